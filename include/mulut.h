@@ -1,0 +1,126 @@
+/*
+ * mulut.h -- C ABI of libmulut_hip.so: MuLUT LUT inference (4D LUT retrieval + 4-simplex
+ * interpolation over rotated s/d/y patches, cascaded stages) on AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the hot path of the reference's `sr/4_test_lut.py`.  The
+ * reference is pure Python and has no FFI layer; each entry point below states which reference
+ * lines it replaces (paths relative to the reference repo root), and INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions: every call returns MULUT_OK (0) or a negative MULUT_E* code;
+ *     mulut_strerror() names it.
+ *   - all image buffers are CALLER-OWNED DEVICE pointers (e.g. torch tensor data_ptr()); the
+ *     library owns only its context: device copies of the tables and an intermediate-stage
+ *     workspace.  LUT rows passed to mulut_set_lut() are HOST pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     stream-ordered and asynchronous with respect to the host.
+ *   - one context per device; calls on one context must be serialised by the caller.
+ *   - there is NO CPU fallback: without a usable HIP device mulut_create() fails.
+ *
+ * Image layouts
+ *   MULUT_LAYOUT_CHW : planar  [N][C][H][W]   (what FourSimplexInterpFaster receives, :296)
+ *   MULUT_LAYOUT_HWC : packed  [N][H][W][C]   (what PIL / the driver loop holds, :265-270,:301)
+ */
+#ifndef MULUT_H_
+#define MULUT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MULUT_VERSION 100 /* 0.1.0 */
+
+enum {
+    MULUT_OK = 0,
+    MULUT_EINVAL = -1,      /* bad argument (NULL pointer, non-positive size, ...)             */
+    MULUT_EMODE = -2,       /* mode not in {s,d,y}: reference raises ValueError, 4_test_lut.py:54 */
+    MULUT_ENOLUT = -3,      /* table (stage,mode) not set: reference raises from np.load, :333  */
+    MULUT_ESHAPE = -4,      /* table shape does not match (rows, v_num) expected for the stage */
+    MULUT_EUNSUPPORTED = -5,/* interval != 4, scale not in 1..4, stages/modes beyond limits    */
+    MULUT_EHIP = -6,        /* a HIP runtime call failed (mulut_last_hip_error() has the text) */
+    MULUT_ENODEVICE = -7,   /* no usable gfx950 device: there is no CPU path                   */
+    MULUT_ENOTCONFIGURED = -8,
+    MULUT_EWORKSPACE = -9   /* strip/halo bookkeeping inconsistent with the buffers given     */
+};
+
+enum { MULUT_LAYOUT_CHW = 0, MULUT_LAYOUT_HWC = 1 };
+
+#define MULUT_MAX_STAGES 8
+#define MULUT_MAX_MODES 8
+
+typedef struct mulut_ctx mulut_ctx;
+
+int mulut_version(void);
+const char *mulut_strerror(int err);
+/* text of the last failing HIP call on this context (empty string if none) */
+const char *mulut_last_hip_error(const mulut_ctx *ctx);
+
+/* Bind a context to HIP device `device_id`. */
+int mulut_create(int device_id, mulut_ctx **out_ctx);
+int mulut_destroy(mulut_ctx *ctx);
+
+/* The model shape: replaces the options the reference reads from TestOptions
+ * (common/option.py:21-23,17: --stages --modes --interval --scale) at sr/4_test_lut.py:279-287.
+ * `modes` is a NUL-terminated string iterated character-wise exactly like `opt.modes` (:287).
+ * Only interval == 4 (q=16, L=17, 83521 rows) is supported -- the only value for which the
+ * reference's reader and writers agree on file names. */
+int mulut_configure(mulut_ctx *ctx, int stages, const char *modes, int scale, int interval);
+
+/* Upload one table: replaces
+ *   lutDict["s{stage}_{mode}"] = np.load(path).astype(np.float32).reshape(-1, v_num)
+ * (sr/4_test_lut.py:322-333).  `host_rows` is the int8 C-order content of the .npy file,
+ * rows = 17^4 = 83521, vnum = scale*scale for the last stage, 1 otherwise.  stage is 1-based. */
+int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows, int64_t rows, int vnum);
+
+/* One (table, mode, rotation) pass: replaces FourSimplexInterpFaster(weight, img_in, h, w,
+ * interval, rot=4-r, upscale, mode) (sr/4_test_lut.py:14-237) TOGETHER WITH the caller's
+ * np.rot90(img, r) + edge pad (:294-296).  in_chw: device uint8 planar [C][H][W], un-rotated,
+ * un-padded.  out_q: device int32 planar [C][H*u][W*u] = q * (the float64 array the reference
+ * returns), exact.  u = scale if `stage` is the last configured stage, else 1. */
+int mulut_pass(mulut_ctx *ctx, int stage, char mode, int r, const uint8_t *in_chw, int H, int W, int C,
+               int32_t *out_q, void *stream);
+
+/* One whole stage (all modes x 4 rotations, average, +bias, round-half-even, clip): replaces one
+ * iteration of the `for s in range(stages)` body (sr/4_test_lut.py:280-306).  N images. */
+int mulut_stage(mulut_ctx *ctx, int stage, const uint8_t *in, int in_layout, uint8_t *out, int out_layout, int N,
+                int H, int W, int C, void *stream);
+
+/* The whole cascade for N images: replaces sr/4_test_lut.py:279-306 (= sr/5_test_lut.py:271-307).
+ * in: N x (H,W,C) uint8, out: N x (H*scale, W*scale, C) uint8, both in `layout`. */
+int mulut_pipeline(mulut_ctx *ctx, const uint8_t *in, uint8_t *out, int N, int H, int W, int C, int layout,
+                   void *stream);
+
+/* Strip form for tile sharding (one strip per GPU).  The logical image is H_full x W; `in` holds
+ * its rows [in_row0, in_row0 + in_rows) and `out` receives output rows for LR rows [y0, y1), i.e.
+ * HR rows [y0*scale, y1*scale), stored from row 0 of `out`.  The input must cover the halo
+ * [y0 - mulut_halo(ctx), y1 + mulut_halo(ctx)) clipped to the image; edge replication happens only
+ * at true image borders, so strips tile bit-exactly. */
+int mulut_pipeline_rows(mulut_ctx *ctx, const uint8_t *in, int in_row0, int in_rows, uint8_t *out, int y0, int y1,
+                        int N, int H_full, int W, int C, int layout, void *stream);
+
+/* LR rows of context needed above/below a strip for the configured cascade (2 per stage: the
+ * reach of the d / y patterns over the four rotations). */
+int mulut_halo(const mulut_ctx *ctx);
+
+/* Pre-size the intermediate-stage workspace so that later pipeline calls allocate nothing
+ * (required before capturing a pipeline call into a hipGraph). */
+int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C);
+
+/* Per-stage device timing for bench.py's roofline leg: when enabled, every mulut_pipeline[_rows]
+ * call brackets each stage's kernel launch with hipEvents recorded on the caller's stream;
+ * mulut_last_stage_ms() waits for the last call's events and returns the elapsed milliseconds of
+ * each stage (n = number of stages written, <= cap).  Off by default (events cost a few us). */
+int mulut_set_stage_timing(mulut_ctx *ctx, int enable);
+int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap);
+
+/* Name of the kernel variant used for the final / non-final stage (for profiles). */
+const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MULUT_H_ */

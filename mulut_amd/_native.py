@@ -1,0 +1,89 @@
+"""Builds and loads libmulut_hip.so (the C ABI of include/mulut.h) with ctypes."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+_LIBDIR = os.path.join(_PKG, "lib")
+LIB_PATH = os.path.join(_LIBDIR, "libmulut_hip.so")
+SOURCES = ["mulut_kernels.hip", "mulut_capi.hip"]
+HEADERS = ["mulut_core.h", "mulut_kernels.h", os.path.join("..", "..", "include", "mulut.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall"]
+
+# every symbol include/mulut.h declares
+EXPORTS = [
+    "mulut_version", "mulut_strerror", "mulut_last_hip_error", "mulut_create", "mulut_destroy",
+    "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage", "mulut_pipeline",
+    "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing", "mulut_last_stage_ms",
+    "mulut_kernel_name",
+]
+
+_lib = None
+
+
+def _hipcc():
+    return shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(_CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension in-tree for gfx950 (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = _hipcc()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot build libmulut_hip.so (no CPU fallback exists)")
+    os.makedirs(_LIBDIR, exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=_CSRC)
+    return LIB_PATH
+
+
+def load():
+    """Return the ctypes handle; builds the library first if its sources are newer."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if needs_build():
+        if _hipcc() is not None:
+            build()
+        elif not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmulut_hip.so is missing and hipcc is unavailable; "
+                               "run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = ctypes.CDLL(LIB_PATH)
+    i, p, c_char_p, i64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64
+    L.mulut_version.restype = i
+    L.mulut_strerror.argtypes = [i]
+    L.mulut_strerror.restype = c_char_p
+    L.mulut_last_hip_error.argtypes = [p]
+    L.mulut_last_hip_error.restype = c_char_p
+    L.mulut_create.argtypes = [i, ctypes.POINTER(p)]
+    L.mulut_destroy.argtypes = [p]
+    L.mulut_configure.argtypes = [p, i, c_char_p, i, i]
+    L.mulut_set_lut.argtypes = [p, i, ctypes.c_char, p, i64, i]
+    L.mulut_pass.argtypes = [p, i, ctypes.c_char, i, p, i, i, i, p, p]
+    L.mulut_stage.argtypes = [p, i, p, i, p, i, i, i, i, i, p]
+    L.mulut_pipeline.argtypes = [p, p, p, i, i, i, i, i, p]
+    L.mulut_pipeline_rows.argtypes = [p, p, i, i, p, i, i, i, i, i, i, i, p]
+    L.mulut_halo.argtypes = [p]
+    L.mulut_reserve.argtypes = [p, i, i, i, i]
+    L.mulut_set_stage_timing.argtypes = [p, i]
+    L.mulut_last_stage_ms.argtypes = [p, ctypes.POINTER(ctypes.c_float), i]
+    L.mulut_kernel_name.argtypes = [p, i]
+    L.mulut_kernel_name.restype = c_char_p
+    for name in ("mulut_create", "mulut_destroy", "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage",
+                 "mulut_pipeline", "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing",
+                 "mulut_last_stage_ms"):
+        getattr(L, name).restype = i
+    _lib = L
+    return L

@@ -1,0 +1,357 @@
+// mulut_capi.hip -- implementation of the C ABI declared in include/mulut.h.
+// Owns: the context (device id, model shape), device copies of the tables, the ping-pong
+// workspace for intermediate stage images.  All image buffers belong to the caller.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mulut.h"
+#include "mulut_kernels.h"
+
+using namespace mulut;
+
+struct DevTable {
+    void *dev = nullptr;
+    int vnum = 0;
+    size_t bytes = 0;
+};
+
+struct mulut_ctx {
+    int device = 0;
+    bool configured = false;
+    int stages = 0, n_modes = 0, scale = 0, interval = 0;
+    char modes[MULUT_MAX_MODES + 1] = {0};
+    signed char di[MULUT_MAX_MODES][3], dj[MULUT_MAX_MODES][3];
+    int reach = 2;  // LR rows one stage looks beyond its output rows
+    DevTable tab[MULUT_MAX_STAGES][3];  // [stage-1][pattern id s,d,y]
+    uint8_t *ws[2] = {nullptr, nullptr};
+    size_t ws_bytes = 0;
+    std::string hip_err;
+    bool timing = false;
+    hipEvent_t ev[MULUT_MAX_STAGES + 1] = {};
+    int timed_stages = 0;
+};
+
+static int pattern_id(char m) { return m == 's' ? 0 : m == 'd' ? 1 : m == 'y' ? 2 : -1; }
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            if (ctx) (ctx)->hip_err = std::string(#expr) + ": " + hipGetErrorString(e__);   \
+            return MULUT_EHIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+extern "C" {
+
+int mulut_version(void) { return MULUT_VERSION; }
+
+const char *mulut_strerror(int err) {
+    switch (err) {
+        case MULUT_OK: return "ok";
+        case MULUT_EINVAL: return "invalid argument";
+        case MULUT_EMODE: return "Mode not implemented.";
+        case MULUT_ENOLUT: return "LUT for (stage, mode) not set";
+        case MULUT_ESHAPE: return "LUT shape does not match (83521, v_num) for this stage";
+        case MULUT_EUNSUPPORTED: return "unsupported configuration (interval must be 4, scale 1..4)";
+        case MULUT_EHIP: return "HIP runtime error";
+        case MULUT_ENODEVICE: return "no usable HIP device (there is no CPU path)";
+        case MULUT_ENOTCONFIGURED: return "mulut_configure() has not been called";
+        case MULUT_EWORKSPACE: return "input rows do not cover the strip plus halo";
+        default: return "unknown error";
+    }
+}
+
+const char *mulut_last_hip_error(const mulut_ctx *ctx) { return ctx ? ctx->hip_err.c_str() : ""; }
+
+int mulut_create(int device_id, mulut_ctx **out_ctx) {
+    if (!out_ctx) return MULUT_EINVAL;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MULUT_ENODEVICE;
+    if (device_id < 0 || device_id >= n) return MULUT_EINVAL;
+    mulut_ctx *c = new (std::nothrow) mulut_ctx();
+    if (!c) return MULUT_EINVAL;
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) {
+        delete c;
+        return MULUT_ENODEVICE;
+    }
+    *out_ctx = c;
+    return MULUT_OK;
+}
+
+int mulut_destroy(mulut_ctx *ctx) {
+    if (!ctx) return MULUT_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    for (auto &st : ctx->tab)
+        for (auto &t : st)
+            if (t.dev) (void)hipFree(t.dev);
+    for (auto &w : ctx->ws)
+        if (w) (void)hipFree(w);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete ctx;
+    return MULUT_OK;
+}
+
+int mulut_configure(mulut_ctx *ctx, int stages, const char *modes, int scale, int interval) {
+    if (!ctx || !modes) return MULUT_EINVAL;
+    const size_t M = strlen(modes);
+    if (stages < 1 || stages > MULUT_MAX_STAGES || M < 1 || M > MULUT_MAX_MODES) return MULUT_EUNSUPPORTED;
+    if (interval != kInterval || scale < 1 || scale > 4) return MULUT_EUNSUPPORTED;
+    const int reach = 2;  // tiles always stage a 2-px halo (d / y patterns); s-only models use it too
+    for (size_t m = 0; m < M; ++m) {
+        int di[3], dj[3];
+        if (!pattern_offsets(modes[m], di, dj)) return MULUT_EMODE;
+        for (int k = 0; k < 3; ++k) {
+            ctx->di[m][k] = (signed char)di[k];
+            ctx->dj[m][k] = (signed char)dj[k];
+        }
+    }
+    ctx->stages = stages;
+    ctx->n_modes = (int)M;
+    ctx->scale = scale;
+    ctx->interval = interval;
+    memcpy(ctx->modes, modes, M + 1);
+    ctx->reach = reach;
+    ctx->configured = true;
+    return MULUT_OK;
+}
+
+int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows, int64_t rows, int vnum) {
+    if (!ctx || !host_rows) return MULUT_EINVAL;
+    if (stage < 1 || stage > MULUT_MAX_STAGES) return MULUT_EINVAL;
+    const int pid = pattern_id(mode);
+    if (pid < 0) return MULUT_EMODE;
+    if (rows != kRows) return MULUT_ESHAPE;
+    int u = 0;
+    for (int k = 1; k <= 4; ++k)
+        if (k * k == vnum) u = k;
+    if (!u) return MULUT_ESHAPE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevTable &t = ctx->tab[stage - 1][pid];
+    std::vector<uint8_t> img;
+    if (u == 1) {
+        img.assign(kU1TableBytes, 0);
+        memcpy(img.data(), host_rows, kRows);
+    } else {
+        const int rb = row_dwords(u) * 4;
+        img.assign((size_t)kRows * rb, 128);
+        for (int64_t i = 0; i < kRows; ++i)
+            for (int e = 0; e < vnum; ++e) img[(size_t)i * rb + e] = (uint8_t)((int)host_rows[i * vnum + e] + 128);
+    }
+    if (t.dev && t.bytes != img.size()) {
+        HIP_TRY(ctx, hipFree(t.dev));
+        t.dev = nullptr;
+    }
+    if (!t.dev) HIP_TRY(ctx, hipMalloc(&t.dev, img.size()));
+    HIP_TRY(ctx, hipMemcpy(t.dev, img.data(), img.size(), hipMemcpyHostToDevice));
+    t.vnum = vnum;
+    t.bytes = img.size();
+    return MULUT_OK;
+}
+
+static int stage_u(const mulut_ctx *ctx, int stage) { return stage == ctx->stages ? ctx->scale : 1; }
+
+// Tables of one stage in mode order, shape-checked against the stage's upscale.
+static int stage_tables(const mulut_ctx *ctx, int stage, const void **lut) {
+    const int vnum = stage_u(ctx, stage) * stage_u(ctx, stage);
+    for (int m = 0; m < ctx->n_modes; ++m) {
+        const DevTable &t = ctx->tab[stage - 1][pattern_id(ctx->modes[m])];
+        if (!t.dev) return MULUT_ENOLUT;
+        if (t.vnum != vnum) return MULUT_ESHAPE;
+        lut[m] = t.dev;
+    }
+    return MULUT_OK;
+}
+
+int mulut_pass(mulut_ctx *ctx, int stage, char mode, int r, const uint8_t *in_chw, int H, int W, int C,
+               int32_t *out_q, void *stream) {
+    if (!ctx || !in_chw || !out_q || H <= 0 || W <= 0 || C <= 0 || r < 0 || r > 3) return MULUT_EINVAL;
+    if (!ctx->configured) return MULUT_ENOTCONFIGURED;
+    if (stage < 1 || stage > ctx->stages) return MULUT_EINVAL;
+    const int pid = pattern_id(mode);
+    if (pid < 0) return MULUT_EMODE;
+    const DevTable &t = ctx->tab[stage - 1][pid];
+    if (!t.dev) return MULUT_ENOLUT;
+    const int u = stage_u(ctx, stage);
+    if (t.vnum != u * u) return MULUT_ESHAPE;
+    PassArgs a;
+    a.in = in_chw;
+    a.out = out_q;
+    a.lut = t.dev;
+    a.C = C; a.H = H; a.W = W; a.u = u; a.r = r;
+    int di[3], dj[3];
+    pattern_offsets(mode, di, dj);
+    for (int k = 0; k < 3; ++k) {
+        a.di[k] = (signed char)di[k];
+        a.dj[k] = (signed char)dj[k];
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_pass(a, (hipStream_t)stream));
+    return MULUT_OK;
+}
+
+static View make_view(const uint8_t *p, int layout, int rows, int W, int C, int row0) {
+    View v;
+    v.p = const_cast<uint8_t *>(p);
+    v.row0 = row0;
+    if (layout == MULUT_LAYOUT_HWC) {
+        v.sX = C; v.sC = 1; v.sY = W * C;
+    } else {
+        v.sX = 1; v.sY = W; v.sC = rows * W;
+    }
+    v.sN = (long long)rows * W * C;
+    return v;
+}
+
+// Launch one stage: input view holds LR rows [in.row0, ...), outputs for LR rows [oy0, oy1).
+static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
+                     int C, int oy0, int oy1, hipStream_t st) {
+    StageArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = stage_tables(ctx, stage, a.lut);
+    if (rc) return rc;
+    const bool last = stage == ctx->stages;
+    const int u = stage_u(ctx, stage);
+    a.in = in; a.out = out;
+    a.N = N; a.C = C; a.H = H; a.W = W;
+    a.oy0 = oy0; a.oy1 = oy1;
+    a.M = ctx->n_modes;
+    memcpy(a.di, ctx->di, sizeof(a.di));
+    memcpy(a.dj, ctx->dj, sizeof(a.dj));
+    a.div = make_div_magic((uint32_t)stage_divisor(ctx->n_modes, last));
+    a.bias_num = stage_bias_num(ctx->n_modes, last);
+    int tw, th;
+    if (u == 1) stage_u1_tile(tw, th); else stage_up_tile(tw, th);
+    a.tiles_x = (W + tw - 1) / tw;
+    a.tiles_y = (oy1 - oy0 + th - 1) / th;
+    if (u == 1) {
+        HIP_TRY(ctx, launch_stage_u1(a, st));
+    } else {
+        int mode = kOutGeneric;
+        if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || C == 1)) mode = kOutPlanarU4;
+        else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3) mode = kOutPackedRGBU4;
+        HIP_TRY(ctx, launch_stage_up(a, u, mode, st));
+    }
+    return MULUT_OK;
+}
+
+int mulut_halo(const mulut_ctx *ctx) { return (ctx && ctx->configured) ? ctx->reach * ctx->stages : 0; }
+
+static int ensure_workspace(mulut_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return MULUT_OK;
+    for (auto &w : ctx->ws) {
+        if (w) HIP_TRY(ctx, hipFree(w));
+        w = nullptr;
+    }
+    ctx->ws_bytes = 0;
+    for (auto &w : ctx->ws) HIP_TRY(ctx, hipMalloc((void **)&w, bytes));
+    ctx->ws_bytes = bytes;
+    return MULUT_OK;
+}
+
+int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
+    if (!ctx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MULUT_EINVAL;
+    if (!ctx->configured) return MULUT_ENOTCONFIGURED;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->stages < 2) return MULUT_OK;
+    return ensure_workspace(ctx, (size_t)N * H * W * C);
+}
+
+int mulut_stage(mulut_ctx *ctx, int stage, const uint8_t *in, int in_layout, uint8_t *out, int out_layout, int N,
+                int H, int W, int C, void *stream) {
+    if (!ctx || !in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 3) return MULUT_EINVAL;
+    if (!ctx->configured) return MULUT_ENOTCONFIGURED;
+    if (stage < 1 || stage > ctx->stages) return MULUT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int u = stage_u(ctx, stage);
+    const View vin = make_view(in, in_layout, H, W, C, 0);
+    const View vout = make_view(out, out_layout, H * u, W * u, C, 0);
+    return run_stage(ctx, stage, vin, vout, out_layout, N, H, W, C, 0, H, (hipStream_t)stream);
+}
+
+int mulut_pipeline_rows(mulut_ctx *ctx, const uint8_t *in, int in_row0, int in_rows, uint8_t *out, int y0, int y1,
+                        int N, int H, int W, int C, int layout, void *stream) {
+    if (!ctx || !in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 3) return MULUT_EINVAL;
+    if (!ctx->configured) return MULUT_ENOTCONFIGURED;
+    if (y0 < 0 || y1 > H || y0 >= y1 || in_row0 < 0 || in_rows <= 0 || in_row0 + in_rows > H) return MULUT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int S = ctx->stages, reach = ctx->reach;
+    // rows of each stage's output that the cascade needs
+    int lo[MULUT_MAX_STAGES + 1], hi[MULUT_MAX_STAGES + 1];
+    for (int s = 1; s <= S; ++s) {
+        lo[s] = imax(0, y0 - reach * (S - s));
+        hi[s] = imin(H, y1 + reach * (S - s));
+    }
+    // the caller's band must cover stage 1's reads
+    if (in_row0 > imax(0, lo[1] - reach) || in_row0 + in_rows < imin(H, hi[1] + reach)) return MULUT_EWORKSPACE;
+    if (S > 1) {
+        size_t need = 0;
+        for (int s = 1; s < S; ++s) {
+            const size_t b = (size_t)N * C * (hi[s] - lo[s]) * W;
+            if (b > need) need = b;
+        }
+        int rc = ensure_workspace(ctx, need);
+        if (rc) return rc;
+    }
+    View cur = make_view(in, layout, in_rows, W, C, in_row0);
+    ctx->timed_stages = 0;
+    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], (hipStream_t)stream));
+    for (int s = 1; s <= S; ++s) {
+        const int u = stage_u(ctx, s);
+        View dst;
+        int dst_layout;
+        if (s == S) {
+            dst = make_view(out, layout, (y1 - y0) * u, W * u, C, y0 * u);
+            dst_layout = layout;
+        } else {
+            dst = make_view(ctx->ws[s & 1], MULUT_LAYOUT_CHW, hi[s] - lo[s], W, C, lo[s]);
+            dst_layout = MULUT_LAYOUT_CHW;
+        }
+        int rc = run_stage(ctx, s, cur, dst, dst_layout, N, H, W, C, lo[s], hi[s], (hipStream_t)stream);
+        if (rc) return rc;
+        if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[s], (hipStream_t)stream));
+        cur = dst;
+    }
+    if (ctx->timing) ctx->timed_stages = S;
+    return MULUT_OK;
+}
+
+int mulut_pipeline(mulut_ctx *ctx, const uint8_t *in, uint8_t *out, int N, int H, int W, int C, int layout,
+                   void *stream) {
+    return mulut_pipeline_rows(ctx, in, 0, H, out, 0, H, N, H, W, C, layout, stream);
+}
+
+int mulut_set_stage_timing(mulut_ctx *ctx, int enable) {
+    if (!ctx) return MULUT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (enable)
+        for (auto &e : ctx->ev)
+            if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+    ctx->timing = enable != 0;
+    ctx->timed_stages = 0;
+    return MULUT_OK;
+}
+
+int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap) {
+    if (!ctx || !ms || cap <= 0) return MULUT_EINVAL;
+    const int n = ctx->timed_stages < cap ? ctx->timed_stages : cap;
+    if (n > 0) HIP_TRY(ctx, hipEventSynchronize(ctx->ev[ctx->timed_stages]));
+    for (int s = 0; s < n; ++s) HIP_TRY(ctx, hipEventElapsedTime(&ms[s], ctx->ev[s], ctx->ev[s + 1]));
+    return n;
+}
+
+const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
+    if (!ctx || !ctx->configured) return "";
+    if (!is_final || ctx->scale == 1) return stage_u1_name();
+    return stage_up_name(ctx->scale, ctx->scale == 4 ? kOutPackedRGBU4 : kOutGeneric);
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// mulut_kernels.h -- launch interface between the C ABI (mulut_capi.hip) and the gfx950 kernels
+// (mulut_kernels.hip).  Internal; the public boundary is include/mulut.h.
+#ifndef MULUT_KERNELS_H_
+#define MULUT_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mulut_core.h"
+
+namespace mulut {
+
+constexpr int kMaxModes = 8;
+constexpr int kU1TableBytes = (kRows + 15) & ~15;  // 83536: int8 rows of a v_num==1 table, padded to 16 B
+
+// Byte view of a uint8 image batch restricted to a band of rows:
+//   addr(n, c, y, x) = p + n*sN + c*sC + (y - row0)*sY + x*sX      (y in logical image rows)
+struct View {
+    uint8_t *p;
+    long long sN;
+    int sC, sY, sX;
+    int row0;
+};
+
+// Device-side table formats (chosen at mulut_set_lut time):
+//   v_num == 1 : int8 values as stored in the .npy, kU1TableBytes long (staged whole into LDS)
+//   v_num  > 1 : value + 128 as uint8, row stride row_dwords(u)*4 bytes (one vector load per row)
+__host__ __device__ constexpr int row_dwords(int u) { return (u * u + 3) / 4; }
+
+struct StageArgs {
+    View in, out;
+    int N, C, H, W;         // logical (full-image) size of the stage input
+    int oy0, oy1;           // LR rows whose outputs this launch produces
+    int tiles_x, tiles_y;   // tile grid over [oy0,oy1) x [0,W)
+    int M;                  // number of modes
+    const void *lut[kMaxModes];
+    signed char di[kMaxModes][3], dj[kMaxModes][3];  // pattern offsets of keys b,c,d (rotation 0)
+    DivMagic div;           // epilogue divisor (16*M final, 64*M non-final)
+    int bias_num;           // numerator bias (127*64*M non-final, 0 final)
+};
+
+struct PassArgs {
+    const uint8_t *in;   // planar [C][H][W]
+    int32_t *out;        // planar [C][H*u][W*u]
+    const void *lut;
+    int C, H, W, u, r;
+    signed char di[3], dj[3];
+};
+
+enum K2Out { kOutGeneric = 0, kOutPlanarU4 = 1, kOutPackedRGBU4 = 2 };
+
+hipError_t launch_pass(const PassArgs &a, hipStream_t st);
+// non-final (or u == 1 final) stage: tables staged in LDS, one byte out per site
+hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st);
+// final stage with u in {2,3,4}: u*u bytes out per site
+hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t st);
+void stage_u1_tile(int &tw, int &th);
+void stage_up_tile(int &tw, int &th);
+const char *stage_u1_name();
+const char *stage_up_name(int u, int out_mode);
+
+}  // namespace mulut
+#endif

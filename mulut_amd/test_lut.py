@@ -1,0 +1,85 @@
+"""GPU twin of the reference's LUT test script (sr/4_test_lut.py:240-340; path handling per the fork's
+working copy sr/5_test_lut.py:489-577).
+
+    python -m mulut_amd.test_lut --stages 2 --modes sdy -e ../models/sr_x2sdy
+
+Same inputs ({testDir}/{dataset}/HR/*.png and LR_bicubic/X{scale}/<same name>), same outputs
+({resultRoot}/{basename(expDir)}/{dataset}/X{scale}/{stem}_{lutName}_{8-interval}bit.png), same summary line.
+The per-image stage/mode/rotation loop runs as one `mulut_pipeline` call on the GPU instead of
+`multiprocessing.Pool(24)` over NumPy.
+"""
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .engine import MuLUTEngine
+from .metrics import modcrop, psnr, rgb2ycbcr, ssim
+from .options import TestOptions
+
+
+class eltr:
+    """Same name and role as the reference's evaluator class (sr/4_test_lut.py:240)."""
+
+    def __init__(self, dataset, opt, engine):
+        folder = os.path.join(opt.testDir, dataset, 'HR')
+        files = os.listdir(folder)
+        files.sort()
+        exp_name = opt.expDir.rstrip("/").split("/")[-1]
+        result_path = os.path.join(opt.resultRoot, exp_name, dataset, "X{}".format(opt.scale))
+        os.makedirs(result_path, exist_ok=True)
+        self.result_path = result_path
+        self.dataset = dataset
+        self.files = files
+        self.opt = opt
+        self.engine = engine
+
+    def run(self, num_worker=None):
+        psnr_ssim_s = [self._worker(i) for i in range(len(self.files))]
+        arr = np.asarray(psnr_ssim_s)
+        print('Dataset {} | AVG LUT PSNR: {:.2f} SSIM: {:.4f}'.format(self.dataset, np.mean(arr[:, 0]),
+                                                                      np.mean(arr[:, 1])))
+        return arr
+
+    def super_resolve(self, img_lr):
+        """uint8 HWC (or HW gray -> replicated to 3 channels, :268-270) -> uint8 HWC."""
+        if img_lr.ndim == 2:
+            img_lr = np.stack([img_lr] * 3, axis=2)
+        x = torch.from_numpy(np.ascontiguousarray(img_lr)).to(self.engine.device)
+        return self.engine.pipeline(x).cpu().numpy()
+
+    def _worker(self, i):
+        opt = self.opt
+        img_lr = np.array(Image.open(
+            os.path.join(opt.testDir, self.dataset, 'LR_bicubic/X{}'.format(opt.scale), self.files[i])))
+        img_gt = np.array(Image.open(os.path.join(opt.testDir, self.dataset, 'HR', self.files[i])))
+        img_gt = modcrop(img_gt, opt.scale)
+        if img_gt.ndim == 2:
+            img_gt = np.stack([img_gt] * 3, axis=2)
+        img_out = self.super_resolve(img_lr)
+        Image.fromarray(img_out).save(os.path.join(
+            self.result_path, '{}_{}_{}bit.png'.format(self.files[i].split('/')[-1][:-4], opt.lutName,
+                                                       8 - opt.interval)))
+        y_gt, y_out = rgb2ycbcr(img_gt)[:, :, 0], rgb2ycbcr(img_out)[:, :, 0]
+        return [psnr(y_gt, y_out, opt.scale), ssim(y_gt, y_out)]
+
+
+def build_engine(opt):
+    eng = MuLUTEngine(opt.device)
+    eng.configure(opt.stages, opt.modes, opt.scale, opt.interval)
+    eng.load_luts(opt.expDir, opt.lutName)     # sr/4_test_lut.py:322-333
+    return eng
+
+
+def main(argv=None):
+    opt = TestOptions().parse(argv)
+    engine = build_engine(opt)
+    results = {}
+    for dataset in opt.datasets.split(","):   # reference: all_datasets = ['Set5'] (:336)
+        results[dataset] = eltr(dataset, opt, engine).run()
+    return results
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,292 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (mulut_amd.engine -> libmulut_hip.so),
+against (a) fixtures produced by running the reference itself, (b) the reference's own Set5 PNGs,
+(c) the CPU oracle on seeded inputs, (d) size-independent properties at the full BASELINE size.
+Bar: bit-exact (integer / byte work)."""
+import os
+import re
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import GOLDEN
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from mulut_amd import MuLUTEngine, MuLUTError, load_lut_dict, synthetic_lut  # noqa: E402
+from mulut_amd.engine import LAYOUT_CHW, LAYOUT_HWC  # noqa: E402
+from oracle import c_oracle  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def eng(shipped_luts):
+    e = MuLUTEngine(0)
+    e.configure(2, "sdy", 4, 4).set_lut_dict(shipped_luts)
+    yield e
+    e.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def natural_image(h, w, c=3, seed=0):
+    """D-natural of SURVEY 8d: low-frequency sinusoids + sigma=2 noise."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    out = np.zeros((h, w, c))
+    for ch in range(c):
+        acc = np.zeros((h, w))
+        for _ in range(6):
+            fy, fx = rng.uniform(0.5, 6.0, 2) * 2 * np.pi / max(h, w)
+            acc += rng.uniform(0.3, 1.0) * np.sin(fy * yy + fx * xx + rng.uniform(0, 2 * np.pi))
+        acc = (acc - acc.min()) / (acc.max() - acc.min()) * 255.0
+        out[:, :, ch] = acc + rng.normal(0, 2, (h, w))
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------
+# (a) fixtures from the reference
+# ---------------------------------------------------------------------------------------------
+def test_pass_matches_reference_fixtures(eng, pass_fx):
+    n = 0
+    for key in sorted(k for k in pass_fx.files if k.startswith("out/")):
+        _, name, u, mode, r = key.split("/")
+        u, r = int(u[1:]), int(r[1:])
+        img = pass_fx["in/" + name].transpose(2, 0, 1)
+        got = eng.pass_q(2 if u == 4 else 1, mode, r, dev(img)).cpu().numpy()
+        assert np.array_equal(got, pass_fx[key]), key
+        n += 1
+    assert n == 168
+
+
+def test_interp_twin_has_reference_signature_and_values(pass_fx, shipped_luts):
+    from mulut_amd import FourSimplexInterpFaster
+    for name in ("rand_19x13x3", "ties_9x11x3", "one_1x1x1"):
+        img = pass_fx["in/" + name].astype(np.float32)
+        for u, st in ((1, 1), (4, 2)):
+            for mode in "sdy":
+                pad = 1 if mode == "s" else 2
+                for r in range(4):
+                    rimg = np.rot90(img, r)
+                    h, w, _ = rimg.shape
+                    img_in = np.pad(rimg, ((0, pad), (0, pad), (0, 0)), mode="edge").transpose(2, 0, 1)
+                    weight = shipped_luts["s%d_%s" % (st, mode)].astype(np.float32)
+                    out = FourSimplexInterpFaster(weight, img_in, h, w, 4, 4 - r, upscale=u, mode=mode)
+                    assert out.dtype == np.float64
+                    assert np.array_equal(out * 16, pass_fx["out/%s/u%d/%s/r%d" % (name, u, mode, r)])
+    with pytest.raises(ValueError, match="Mode x not implemented."):
+        FourSimplexInterpFaster(np.zeros((17 ** 4, 1), np.float32), np.zeros((1, 4, 4), np.float32), 3, 3, 4, 0, 1, "x")
+
+
+def test_two_stage_sdy_matches_reference(eng, pipe_fx):
+    for name in sorted({k.split("/")[1] for k in pipe_fx.files if k.startswith("s2sdy/")}):
+        img = pipe_fx["in/" + name]
+        st1 = eng.stage(1, dev(img)).cpu().numpy()
+        assert np.array_equal(st1, pipe_fx["s2sdy/%s/stage1" % name]), name
+        fin = eng.pipeline(dev(img)).cpu().numpy()
+        assert np.array_equal(fin, pipe_fx["s2sdy/%s/final" % name]), name
+        # planar layout gives the same bytes
+        chw = eng.pipeline(dev(img.transpose(2, 0, 1)), layout=LAYOUT_CHW).cpu().numpy()
+        assert np.array_equal(chw.transpose(1, 2, 0), fin), name
+
+
+def test_other_configs_match_reference(pipe_fx):
+    e = MuLUTEngine(0)
+    keys = sorted({"/".join(k.split("/")[:2]) for k in pipe_fx.files if k.startswith("synth_")})
+    assert len(keys) >= 20
+    for key in keys:
+        cfg, name = key.split("/")
+        m = re.match(r"synth_S(\d)_([sdy]+)_x(\d)", cfg)
+        stages, modes, scale = int(m.group(1)), m.group(2), int(m.group(3))
+        e.configure(stages, modes, scale, 4)
+        for s in range(stages):
+            for mode in modes:
+                seed = 1000 * stages + 100 * scale + 10 * s + "sdy".index(mode)
+                e.set_lut(s + 1, mode, synthetic_lut(seed, scale * scale if s + 1 == stages else 1))
+        img = pipe_fx["in/" + name]
+        fin = e.pipeline(dev(img)).cpu().numpy()
+        assert np.array_equal(fin, pipe_fx["%s/stage%d" % (key, stages)]), key
+        cur = dev(img)
+        for s in range(stages - 1):
+            cur = e.stage(s + 1, cur)
+            assert np.array_equal(cur.cpu().numpy(), pipe_fx["%s/stage%d" % (key, s + 1)]), (key, s)
+    e.close()
+
+
+def test_config1_single_stage_s(pipe_fx, shipped_luts):
+    e = MuLUTEngine(0).configure(1, "s", 4, 4)
+    e.set_lut(1, "s", shipped_luts["s2_s"])
+    for name in ("rand_19x13x3", "smooth_24x20x3"):
+        got = e.pipeline(dev(pipe_fx["in/" + name])).cpu().numpy()
+        assert np.array_equal(got, pipe_fx["cfg1_s2s_as_s1/%s/final" % name])
+    e.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# (b) the reference's own golden outputs: Set5, through the CLI twin
+# ---------------------------------------------------------------------------------------------
+def test_cli_reproduces_set5_pngs_and_psnr(tmp_path, capsys):
+    from mulut_amd import test_lut
+    test_dir = tmp_path / "SRBenchmark"
+    (test_dir / "Set5").mkdir(parents=True)
+    os.symlink(os.path.join(GOLDEN, "Set5", "HR"), test_dir / "Set5" / "HR")
+    os.symlink(os.path.join(GOLDEN, "Set5", "LR_bicubic"), test_dir / "Set5" / "LR_bicubic")
+    exp = tmp_path / "models" / "sr_x2sdy"
+    exp.mkdir(parents=True)
+    for fn in os.listdir(os.path.join(GOLDEN, "luts")):
+        os.symlink(os.path.join(GOLDEN, "luts", fn), exp / fn)
+    res = test_lut.main(["--stages", "2", "--modes", "sdy", "-e", str(exp), "--testDir", str(test_dir),
+                         "--resultRoot", str(tmp_path / "results")])
+    line = capsys.readouterr().out.strip().splitlines()[-1]
+    assert line == "Dataset Set5 | AVG LUT PSNR: 30.61 SSIM: 0.8656" or line.startswith(
+        "Dataset Set5 | AVG LUT PSNR: 30.61 SSIM: 0.865")       # reference prints 30.61 / 0.8655 (:343)
+    assert res["Set5"].shape == (5, 2)
+    out_dir = tmp_path / "results" / "sr_x2sdy" / "Set5" / "X4"
+    for fn in sorted(os.listdir(os.path.join(GOLDEN, "Set5", "ref_out"))):
+        want = np.array(Image.open(os.path.join(GOLDEN, "Set5", "ref_out", fn)))
+        got = np.array(Image.open(out_dir / fn))              # same file naming as the reference (:311)
+        assert np.array_equal(got, want), fn
+
+
+def test_gray_input_is_replicated_like_the_reference(eng, pipe_fx):
+    from mulut_amd.test_lut import eltr
+    gray = pipe_fx["in/rand_8x31x1"][:, :, 0]
+    obj = eltr.__new__(eltr)
+    obj.engine = eng
+    out = obj.super_resolve(gray)
+    want = np.repeat(pipe_fx["s2sdy/rand_8x31x1/final"], 3, axis=2)
+    assert np.array_equal(out, want)
+
+
+# ---------------------------------------------------------------------------------------------
+# (c) seeded inputs vs the CPU oracle, edge shapes, batches, layouts
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 1, 3), (1, 7, 1), (9, 1, 3), (2, 2, 3), (33, 65, 3), (64, 32, 3), (65, 129, 3),
+                                   (31, 200, 1), (100, 37, 2)])
+def test_shapes_vs_oracle(eng, shipped_luts, shape):
+    img = np.random.default_rng(sum(shape)).integers(0, 256, shape, dtype=np.uint8)
+    got = eng.pipeline(dev(img)).cpu().numpy()
+    assert np.array_equal(got, c_oracle.pipeline(shipped_luts, 2, "sdy", 4, img))
+
+
+def test_batch_and_natural_vs_oracle(eng, shipped_luts):
+    imgs = np.stack([natural_image(70, 150, 3, seed=s) for s in range(3)] +
+                    [np.random.default_rng(9).integers(0, 256, (70, 150, 3), dtype=np.uint8)])
+    got = eng.pipeline(dev(imgs)).cpu().numpy()
+    assert got.shape == (4, 280, 600, 3)
+    for k in range(4):
+        assert np.array_equal(got[k], c_oracle.pipeline(shipped_luts, 2, "sdy", 4, imgs[k])), k
+    # planar batch
+    got_p = eng.pipeline(dev(imgs.transpose(0, 3, 1, 2)), layout=LAYOUT_CHW).cpu().numpy()
+    assert np.array_equal(got_p.transpose(0, 2, 3, 1), got)
+
+
+@pytest.mark.parametrize("scale,stages,modes", [(2, 4, "sdy"), (3, 2, "sd"), (4, 1, "y"), (1, 2, "sdy"), (2, 1, "ss"),
+                                                (4, 3, "ydsd")])
+def test_generic_configs_vs_oracle(scale, stages, modes):
+    e = MuLUTEngine(0).configure(stages, modes, scale, 4)
+    luts = {}
+    for s in range(stages):
+        for mode in set(modes):
+            luts["s%d_%s" % (s + 1, mode)] = synthetic_lut(7 * s + ord(mode), scale * scale if s + 1 == stages else 1)
+    e.set_lut_dict(luts)
+    for C in (1, 2, 3):
+        img = np.random.default_rng(C).integers(0, 256, (37, 53, C), dtype=np.uint8)
+        want = c_oracle.pipeline(luts, stages, modes, scale, img)
+        assert np.array_equal(e.pipeline(dev(img)).cpu().numpy(), want), (scale, stages, modes, C)
+        got_p = e.pipeline(dev(img.transpose(2, 0, 1)), layout=LAYOUT_CHW).cpu().numpy()
+        assert np.array_equal(got_p.transpose(1, 2, 0), want)
+    e.close()
+
+
+def test_extreme_tables_vs_oracle():
+    img = np.random.default_rng(5).integers(0, 256, (40, 40, 3), dtype=np.uint8)
+    e = MuLUTEngine(0).configure(2, "sdy", 4, 4)
+    for val in (127, -128):
+        luts = {"s%d_%s" % (s, m): np.full((17 ** 4, 16 if s == 2 else 1), val, np.int8) for s in (1, 2) for m in "sdy"}
+        e.set_lut_dict(luts)
+        assert np.array_equal(e.pipeline(dev(img)).cpu().numpy(), c_oracle.pipeline(luts, 2, "sdy", 4, img))
+    e.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# error behaviour of the boundary
+# ---------------------------------------------------------------------------------------------
+def test_error_behaviour(shipped_luts):
+    e = MuLUTEngine(0)
+    with pytest.raises(MuLUTError):                       # not configured
+        e.pipeline(torch.zeros((4, 4, 3), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError, match="Mode"):         # reference: ValueError("Mode {} not implemented.")
+        e.configure(2, "sxq", 4, 4)
+    with pytest.raises(MuLUTError):                       # interval != 4
+        e.configure(2, "sdy", 4, 3)
+    e.configure(2, "sdy", 4, 4)
+    with pytest.raises(MuLUTError, match="not set"):      # reference: FileNotFoundError at np.load
+        e.pipeline(torch.zeros((4, 4, 3), dtype=torch.uint8, device="cuda"))
+    e.set_lut_dict(shipped_luts)
+    e.set_lut(2, "s", shipped_luts["s1_s"])               # wrong v_num for the last stage
+    with pytest.raises(MuLUTError, match="shape"):
+        e.pipeline(torch.zeros((4, 4, 3), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(MuLUTError):
+        e.set_lut(1, "s", np.zeros((100, 1), np.int8))
+    with pytest.raises(TypeError):
+        e.pipeline(torch.zeros((4, 4, 3), dtype=torch.float32, device="cuda"))
+    with pytest.raises(TypeError):
+        e.pipeline(torch.zeros((4, 4, 3), dtype=torch.uint8))   # host tensor: no CPU path
+    e.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# strips (tile sharding): seams are bit-exact
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nstrips", [2, 3, 8])
+def test_strips_tile_bit_exactly(eng, nstrips):
+    H, W = 97, 61
+    img = natural_image(H, W, 3, seed=4)
+    full = eng.pipeline(dev(img))
+    halo = eng.halo
+    assert halo == 4
+    bounds = np.linspace(0, H, nstrips + 1).astype(int)
+    parts = []
+    for k in range(nstrips):
+        y0, y1 = int(bounds[k]), int(bounds[k + 1])
+        r0, r1 = max(0, y0 - halo), min(H, y1 + halo)
+        parts.append(eng.pipeline_rows(dev(img[r0:r1]), r0, y0, y1, H))
+    assert torch.equal(torch.cat(parts, 0), full)
+    with pytest.raises(MuLUTError, match="halo"):          # band too small
+        eng.pipeline_rows(dev(img[10:20]), 10, 10, 20, H)
+
+
+# ---------------------------------------------------------------------------------------------
+# (d) BASELINE size (1080x1920x3 -> 4320x7680x3): whole frame vs oracle + size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_full_1080p_frame(eng, shipped_luts):
+    H, W = 1080, 1920
+    nat = natural_image(H, W, 3, seed=0)
+    noise = np.random.default_rng(0).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    batch = dev(np.stack([nat, noise]))
+    out = eng.pipeline(batch)
+    assert out.shape == (2, 4320, 7680, 3)
+    # whole natural frame against the oracle (about 13 s of CPU)
+    assert np.array_equal(out[0].cpu().numpy(), c_oracle.pipeline(shipped_luts, 2, "sdy", 4, nat))
+    # noise frame: three 96x96 windows recomputed by the oracle with a 4-px halo (receptive field)
+    o1 = out[1].cpu().numpy()
+    for (y, x) in ((0, 0), (500, 900), (1080 - 96, 1920 - 96)):
+        y0, y1, x0, x1 = max(0, y - 4), min(H, y + 100), max(0, x - 4), min(W, x + 100)
+        ref = c_oracle.pipeline(shipped_luts, 2, "sdy", 4, noise[y0:y1, x0:x1])
+        ref = ref[(y - y0) * 4:(y - y0 + 96) * 4, (x - x0) * 4:(x - x0 + 96) * 4]
+        assert np.array_equal(o1[y * 4:(y + 96) * 4, x * 4:(x + 96) * 4], ref), (y, x)
+    # rotation covariance: the 4-rotation ensemble commutes with rot90 of the image
+    rot = eng.pipeline(dev(np.ascontiguousarray(np.rot90(noise, 1))))
+    assert torch.equal(rot, torch.rot90(out[1], 1, (0, 1)))
+    # strips == whole frame (8 strips as on 8 GPUs)
+    parts = []
+    for k in range(8):
+        y0, y1 = k * 135, (k + 1) * 135
+        r0, r1 = max(0, y0 - 4), min(H, y1 + 4)
+        parts.append(eng.pipeline_rows(dev(noise[r0:r1]), r0, y0, y1, H))
+    assert torch.equal(torch.cat(parts, 0), out[1])
+    # determinism
+    assert torch.equal(eng.pipeline(batch), out)
