@@ -43,7 +43,7 @@ def FourSimplexInterpFaster(weight, img_in, h, w, interval, rot, upscale=4, mode
     if not np.array_equal(u8.astype(core.dtype), core):
         raise ValueError("img_in must hold integer values in 0..255")
     r = (4 - rot) % 4                                   # the driver passes rot = 4 - r (:297)
-    unrot = np.ascontiguousarray(np.rot90(u8, -r, axes=(1, 2)))   # undo the driver's np.rot90(img, r)
+    unrot = np.rot90(u8, -r, axes=(1, 2)).copy(order="C")          # undo the driver's np.rot90(img, r)
     eng = _engine(device)
     # a throw-away 1-stage model whose only stage is this table (u = upscale)
     eng.configure(1, mode, scale=upscale, interval=interval)

@@ -28,7 +28,7 @@ def eng(shipped_luts):
 
 
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return torch.from_numpy(np.array(a, order="C", copy=True)).cuda()
 
 
 def natural_image(h, w, c=3, seed=0):
