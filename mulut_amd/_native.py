@@ -20,7 +20,7 @@ EXPORTS = [
     "mulut_kernel_name",
 ]
 
-_lib = None
+_libs = {}
 
 
 def _hipcc():
@@ -49,18 +49,19 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
-def load():
-    """Return the ctypes handle; builds the library first if its sources are newer."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if needs_build():
+def load(path=None):
+    """Return the ctypes handle; builds the library first if its sources are newer.
+    `path` (or $MULUT_LIB) selects another build of the same ABI, e.g. an A/B kernel variant."""
+    path = path or os.environ.get("MULUT_LIB") or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if path == LIB_PATH and needs_build():
         if _hipcc() is not None:
             build()
         elif not os.path.exists(LIB_PATH):
             raise RuntimeError("libmulut_hip.so is missing and hipcc is unavailable; "
                                "run `python -c 'import __graft_entry__ as g; g.build()'`")
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     i, p, c_char_p, i64 = ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64
     L.mulut_version.restype = i
     L.mulut_strerror.argtypes = [i]
@@ -85,5 +86,5 @@ def load():
                  "mulut_pipeline", "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing",
                  "mulut_last_stage_ms"):
         getattr(L, name).restype = i
-    _lib = L
+    _libs[path] = L
     return L

@@ -14,6 +14,14 @@
 
 #include "mulut_kernels.h"
 
+// MULUT_ABLATE selects timing-only variants (wrong results!) built by tools/ab_bench.py into
+// build/ablate/; the shipped library is always built with MULUT_ABLATE == 0.
+//   K2:  1 every row gather reads row 0   2 no gathers (rows synthesised)   3 gathers, no SWAR fma
+//   K1: 11 every LUT read hits byte 0     12 no LUT reads                   13 no table staging
+#ifndef MULUT_ABLATE
+#define MULUT_ABLATE 0
+#endif
+
 namespace mulut {
 
 // ------------------------------------------------------------------------------------------
@@ -130,11 +138,13 @@ __global__ void __launch_bounds__(NT) stage_u1_kernel(StageArgs a) {
 
     for (int m = 0; m < a.M; ++m) {
         __syncthreads();  // tile filled (m == 0) / everyone done with the previous table
+#if MULUT_ABLATE != 13
         {
             const uint4 *src = (const uint4 *)a.lut[m];
             uint4 *dst = (uint4 *)smem;
             for (int i = threadIdx.x; i < kU1TableBytes / 16; i += NT) dst[i] = src[i];
         }
+#endif
         __syncthreads();
         int off[4][3];
 #pragma unroll
@@ -159,8 +169,17 @@ __global__ void __launch_bounds__(NT) stage_u1_kernel(StageArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     int idx[5], w[5];
                     simplex4(va, ctr[off[r][0]], ctr[off[r][1]], ctr[off[r][2]], idx, w);
+#if MULUT_ABLATE == 11
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) idx[j] &= (a.N >> 30);
+#endif
+#if MULUT_ABLATE == 12
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) sum += w[j] * idx[j];
+#else
 #pragma unroll
                     for (int j = 0; j < 5; ++j) sum += w[j] * (int)s_lut[idx[j]];
+#endif
                 }
                 acc[k] += sum;
             }
@@ -263,8 +282,30 @@ __global__ void __launch_bounds__(TW *TH) stage_up_kernel(StageArgs a) {
                 int idx[5], w[5];
                 simplex4(va, v0, v1, v2, idx, w);
                 uint32_t row[5][RW];
+#if MULUT_ABLATE == 1
+#pragma unroll
+                for (int j = 0; j < 5; ++j) idx[j] &= (a.N >> 30);
+#endif
+#if MULUT_ABLATE == 2
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int k = 0; k < RW; ++k) row[j][k] = (uint32_t)idx[j] + k;
+#else
 #pragma unroll
                 for (int j = 0; j < 5; ++j) load_row<U>(lut, idx[j], row[j]);
+#endif
+#if MULUT_ABLATE == 3
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int k = 0; k < RW; ++k) {
+                        if constexpr (r == 0) lo0[k] ^= row[j][k] + w[j];
+                        if constexpr (r == 1) lo1[k] ^= row[j][k] + w[j];
+                        if constexpr (r == 2) lo2[k] ^= row[j][k] + w[j];
+                        if constexpr (r == 3) lo3[k] ^= row[j][k] + w[j];
+                    }
+#else
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                     if constexpr (r == 0) swar_fma<RW>(lo0, hi0, row[j], (uint32_t)w[j]);
@@ -272,6 +313,7 @@ __global__ void __launch_bounds__(TW *TH) stage_up_kernel(StageArgs a) {
                     if constexpr (r == 2) swar_fma<RW>(lo2, hi2, row[j], (uint32_t)w[j]);
                     if constexpr (r == 3) swar_fma<RW>(lo3, hi3, row[j], (uint32_t)w[j]);
                 }
+#endif
             });
         }
         // rotate back + sum the four rotations, remove the +128 bias, divide/round/clip

@@ -21,8 +21,8 @@ class MuLUTEngine:
     """Owns a ``mulut_ctx``.  Mirrors what the reference keeps in ``opt`` + ``lutDict``
     (sr/4_test_lut.py:320-333) and runs its stage loop (:279-306) on the GPU."""
 
-    def __init__(self, device=0):
-        self._lib = _native.load()
+    def __init__(self, device=0, lib_path=None):
+        self._lib = _native.load(lib_path)
         if not torch.cuda.is_available():
             raise MuLUTError("no GPU visible: mulut_amd has no CPU path")
         self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)

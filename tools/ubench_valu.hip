@@ -1,0 +1,123 @@
+// ubench_valu.hip -- issue cost of individual gfx950 VALU instructions, measured in shader cycles
+// (s_memtime) with inline asm so the compiler can neither fold nor re-select them.
+//   hipcc --offload-arch=gfx950 -O3 -o build/ubench_valu tools/ubench_valu.hip && build/ubench_valu
+// One workgroup per CU; W waves per SIMD; each wave runs ITER x 32 independent instructions
+// (8 destination registers, round robin).  Reported: cycles per wave-instruction per SIMD.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+#define DEFKERNEL(NAME, ASM3)                                                                         \
+    __global__ void __launch_bounds__(1024) k_##NAME(unsigned long long *cyc, uint32_t *sink, int iters) { \
+        uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        uint32_t b = threadIdx.x * 3u + 7u, c = threadIdx.x ^ 0x55u;                                  \
+        __syncthreads();                                                                              \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
+        for (int i = 0; i < iters; ++i) {                                                             \
+            asm volatile(ASM3("%0") ASM3("%1") ASM3("%2") ASM3("%3") ASM3("%4") ASM3("%5") ASM3("%6") ASM3("%7") \
+                         ASM3("%0") ASM3("%1") ASM3("%2") ASM3("%3") ASM3("%4") ASM3("%5") ASM3("%6") ASM3("%7") \
+                         ASM3("%0") ASM3("%1") ASM3("%2") ASM3("%3") ASM3("%4") ASM3("%5") ASM3("%6") ASM3("%7") \
+                         ASM3("%0") ASM3("%1") ASM3("%2") ASM3("%3") ASM3("%4") ASM3("%5") ASM3("%6") ASM3("%7") \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)     \
+                         : "v"(b), "v"(c));                                                           \
+        }                                                                                             \
+        asm volatile("s_nop 0" ::: "memory");                                                         \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;          \
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;             \
+    }
+
+// each ASM macro: D = op(D, b, c) on register D
+#define A_ADD(D) "v_add_u32 " D ", " D ", %8\n"
+#define A_AND(D) "v_and_b32 " D ", " D ", %8\n"
+#define A_LSHR(D) "v_lshrrev_b32 " D ", 4, " D "\n"
+#define A_MIN(D) "v_min_u32 " D ", " D ", %8\n"
+#define A_MAX(D) "v_max_u32 " D ", " D ", %8\n"
+#define A_MIN3(D) "v_min3_u32 " D ", " D ", %8, %9\n"
+#define A_MED3(D) "v_med3_i32 " D ", " D ", %8, %9\n"
+#define A_MAD24(D) "v_mad_u32_u24 " D ", " D ", %8, %9\n"
+#define A_MUL24(D) "v_mul_u32_u24 " D ", " D ", %8\n"
+#define A_MULLO(D) "v_mul_lo_u32 " D ", " D ", %8\n"
+#define A_MULHI(D) "v_mul_hi_u32 " D ", " D ", %8\n"
+#define A_PERM(D) "v_perm_b32 " D ", " D ", %8, %9\n"
+#define A_DOT4(D) "v_dot4_u32_u8 " D ", " D ", %8, %9\n"
+#define A_PKMAD(D) "v_pk_mad_u16 " D ", " D ", %8, %9\n"
+#define A_PKMIN(D) "v_pk_min_u16 " D ", " D ", %8\n"
+#define A_PKADD(D) "v_pk_add_u16 " D ", " D ", %8\n"
+#define A_BFE(D) "v_bfe_u32 " D ", " D ", 4, 8\n"
+#define A_LSHLOR(D) "v_lshl_or_b32 " D ", " D ", 3, %8\n"
+#define A_ANDOR(D) "v_and_or_b32 " D ", " D ", %8, %9\n"
+#define A_ADD3(D) "v_add3_u32 " D ", " D ", %8, %9\n"
+#define A_LSHLADD(D) "v_lshl_add_u32 " D ", " D ", 2, %8\n"
+#define A_SUBSDWA(D) "v_sub_u32_sdwa " D ", " D ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n"
+#define A_CVTF(D) "v_cvt_f32_u32 " D ", " D "\n"
+#define A_CVTFSDWA(D) "v_cvt_f32_u32_sdwa " D ", " D " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+#define A_RNDNE(D) "v_rndne_f32 " D ", " D "\n"
+#define A_MULF(D) "v_mul_f32 " D ", " D ", %8\n"
+#define A_FMA(D) "v_fma_f32 " D ", " D ", %8, %9\n"
+#define A_CVTPK(D) "v_cvt_pk_u8_f32 " D ", " D ", 1, %8\n"
+#define A_ALIGN(D) "v_alignbit_b32 " D ", " D ", %8, 16\n"
+#define A_CNDMASK(D) "v_cndmask_b32 " D ", " D ", %8, vcc\n"
+#define A_MOV(D) "v_mov_b32 " D ", %8\n"
+#define A_XAD(D) "v_xad_u32 " D ", " D ", %8, %9\n"
+#define A_MADI24(D) "v_mad_i32_i24 " D ", " D ", %8, %9\n"
+#define A_BFI(D) "v_bfi_b32 " D ", " D ", %8, %9\n"
+#define A_SAD(D) "v_sad_u8 " D ", " D ", %8, %9\n"
+#define A_MQSAD(D) "v_msad_u8 " D ", " D ", %8, %9\n"
+
+#define OPS(X)                                                                                                       \
+    X(ADD) X(AND) X(LSHR) X(MIN) X(MAX) X(MIN3) X(MED3) X(MAD24) X(MUL24) X(MULLO) X(MULHI) X(PERM) X(DOT4) X(PKMAD)   \
+    X(PKMIN) X(PKADD) X(BFE) X(LSHLOR) X(ANDOR) X(ADD3) X(LSHLADD) X(SUBSDWA) X(CVTF) X(CVTFSDWA) X(RNDNE) X(MULF)    \
+    X(FMA) X(CVTPK) X(ALIGN) X(CNDMASK) X(MOV) X(XAD) X(MADI24) X(BFI) X(SAD) X(MQSAD)
+
+#define MK(N) DEFKERNEL(N, A_##N)
+OPS(MK)
+
+typedef void (*kfn)(unsigned long long *, uint32_t *, int);
+struct Ent { const char *name; kfn fn; };
+#define ENT(N) {#N, k_##N},
+static Ent ents[] = {OPS(ENT)};
+
+int main() {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    unsigned long long *cyc;
+    uint32_t *sink;
+    const int ncu = prop.multiProcessorCount;
+    CK(hipMalloc(&cyc, ncu * 16 * 8));
+    CK(hipMalloc(&sink, ncu * 1024 * 4));
+    const int iters = 2000;
+    printf("%-10s", "op");
+    const int wps[] = {1, 2, 4};
+    for (int w : wps) printf("  %dw/SIMD", w);
+    printf("   (cycles per wave-instruction per SIMD, median over waves)\n");
+    for (auto &e : ents) {
+        printf("%-10s", e.name);
+        for (int w : wps) {
+            const int threads = w * 4 * 64;
+            hipLaunchKernelGGL(e.fn, dim3(ncu), dim3(threads), 0, 0, cyc, sink, iters);
+            CK(hipDeviceSynchronize());
+            hipLaunchKernelGGL(e.fn, dim3(ncu), dim3(threads), 0, 0, cyc, sink, iters);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h(ncu * 16);
+            CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> v;
+            for (int b = 0; b < ncu; ++b)
+                for (int k = 0; k < w * 4; ++k) v.push_back((double)h[b * 16 + k]);
+            std::sort(v.begin(), v.end());
+            const double med = v[v.size() / 2];
+            // a wave issues iters*32 instructions in `med` cycles while sharing its SIMD with w-1 others
+            printf("  %7.2f", med / (iters * 32.0) / w);
+        }
+        printf("\n");
+    }
+    return 0;
+}
