@@ -17,7 +17,7 @@ EXPORTS = [
     "mulut_version", "mulut_strerror", "mulut_last_hip_error", "mulut_create", "mulut_destroy",
     "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage", "mulut_pipeline",
     "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing", "mulut_last_stage_ms",
-    "mulut_kernel_name",
+    "mulut_set_tuning", "mulut_kernel_name",
 ]
 
 _libs = {}
@@ -80,11 +80,12 @@ def load(path=None):
     L.mulut_reserve.argtypes = [p, i, i, i, i]
     L.mulut_set_stage_timing.argtypes = [p, i]
     L.mulut_last_stage_ms.argtypes = [p, ctypes.POINTER(ctypes.c_float), i]
+    L.mulut_set_tuning.argtypes = [p, c_char_p, i]
     L.mulut_kernel_name.argtypes = [p, i]
     L.mulut_kernel_name.restype = c_char_p
     for name in ("mulut_create", "mulut_destroy", "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage",
                  "mulut_pipeline", "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing",
-                 "mulut_last_stage_ms"):
+                 "mulut_last_stage_ms", "mulut_set_tuning"):
         getattr(L, name).restype = i
     _libs[path] = L
     return L

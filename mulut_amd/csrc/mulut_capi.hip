@@ -15,7 +15,8 @@
 using namespace mulut;
 
 struct DevTable {
-    void *dev = nullptr;
+    void *dev = nullptr;    // full table image
+    void *band = nullptr;   // diagonal band image (v_num == 16 only), kBandRows x 16 B
     int vnum = 0;
     size_t bytes = 0;
 };
@@ -31,6 +32,9 @@ struct mulut_ctx {
     uint8_t *ws[2] = {nullptr, nullptr};
     size_t ws_bytes = 0;
     std::string hip_err;
+    int num_cus = 256;
+    int final_kernel = 0;   // 0 auto, 1 full-table gather kernel, 2 LDS band kernel
+    int f32_ok[2] = {0, 0}; // float epilogue proven exact for the [non-final, final] divisor
     bool timing = false;
     hipEvent_t ev[MULUT_MAX_STAGES + 1] = {};
     int timed_stages = 0;
@@ -82,6 +86,9 @@ int mulut_create(int device_id, mulut_ctx **out_ctx) {
         delete c;
         return MULUT_ENODEVICE;
     }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+        c->num_cus = prop.multiProcessorCount;
     *out_ctx = c;
     return MULUT_OK;
 }
@@ -91,7 +98,10 @@ int mulut_destroy(mulut_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto &st : ctx->tab)
         for (auto &t : st)
+        {
             if (t.dev) (void)hipFree(t.dev);
+            if (t.band) (void)hipFree(t.band);
+        }
     for (auto &w : ctx->ws)
         if (w) (void)hipFree(w);
     for (auto &e : ctx->ev)
@@ -120,6 +130,12 @@ int mulut_configure(mulut_ctx *ctx, int stages, const char *modes, int scale, in
     ctx->interval = interval;
     memcpy(ctx->modes, modes, M + 1);
     ctx->reach = reach;
+    for (int last = 0; last < 2; ++last) {
+        const DivMagic dm = make_div_magic((uint32_t)stage_divisor((int)M, last != 0));
+        const int span = 128 * kQ * 4 * (int)M;      // |q * sum| <= 128 * 16 * 4M
+        ctx->f32_ok[last] = rhe_f32_valid(-span + stage_bias_num((int)M, last != 0), span + stage_bias_num((int)M, last != 0),
+                                          dm, 1.0f / (float)dm.d) ? 1 : 0;
+    }
     ctx->configured = true;
     return MULUT_OK;
 }
@@ -154,6 +170,22 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
     HIP_TRY(ctx, hipMemcpy(t.dev, img.data(), img.size(), hipMemcpyHostToDevice));
     t.vnum = vnum;
     t.bytes = img.size();
+    if (u == 4) {
+        // diagonal band (mulut_core.h): rows (A,B,C,D) with B-A, C-A, D-A in [-2,2], at band_slot()
+        std::vector<uint8_t> band((size_t)kBandRows * 16, 128);
+        for (int A = 0; A < kL; ++A)
+            for (int B = imax(0, A - 2); B <= imin(kL - 1, A + 2); ++B)
+                for (int C = imax(0, A - 2); C <= imin(kL - 1, A + 2); ++C)
+                    for (int D = imax(0, A - 2); D <= imin(kL - 1, A + 2); ++D) {
+                        const size_t full = (size_t)A * kStrideA + B * kStrideB + C * kStrideC + D;
+                        memcpy(&band[(size_t)band_slot(A, B, C, D) * 16], &img[full * 16], 16);
+                    }
+        if (!t.band) HIP_TRY(ctx, hipMalloc(&t.band, band.size()));
+        HIP_TRY(ctx, hipMemcpy(t.band, band.data(), band.size(), hipMemcpyHostToDevice));
+    } else if (t.band) {
+        HIP_TRY(ctx, hipFree(t.band));
+        t.band = nullptr;
+    }
     return MULUT_OK;
 }
 
@@ -224,12 +256,18 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.oy0 = oy0; a.oy1 = oy1;
     a.M = ctx->n_modes;
-    memcpy(a.di, ctx->di, sizeof(a.di));
-    memcpy(a.dj, ctx->dj, sizeof(a.dj));
+    for (int m = 0; m < ctx->n_modes; ++m)
+        for (int k = 0; k < 3; ++k) {
+            a.di[m][k] = ctx->di[m][k];
+            a.dj[m][k] = ctx->dj[m][k];
+        }
     a.div = make_div_magic((uint32_t)stage_divisor(ctx->n_modes, last));
     a.bias_num = stage_bias_num(ctx->n_modes, last);
+    a.inv_d = 1.0f / (float)a.div.d;
+    a.use_f32 = ctx->f32_ok[last ? 1 : 0];
+    const bool band = u == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1;
     int tw, th;
-    if (u == 1) stage_u1_tile(tw, th); else stage_up_tile(tw, th);
+    if (u == 1) stage_u1_tile(tw, th); else if (band) stage_band_tile(tw, th); else stage_up_tile(tw, th);
     a.tiles_x = (W + tw - 1) / tw;
     a.tiles_y = (oy1 - oy0 + th - 1) / th;
     if (u == 1) {
@@ -238,7 +276,13 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         int mode = kOutGeneric;
         if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || C == 1)) mode = kOutPlanarU4;
         else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3) mode = kOutPackedRGBU4;
-        HIP_TRY(ctx, launch_stage_up(a, u, mode, st));
+        if (band) {
+            BandArgs b;
+            for (int m = 0; m < ctx->n_modes; ++m) b.band[m] = ctx->tab[stage - 1][pattern_id(ctx->modes[m])].band;
+            HIP_TRY(ctx, launch_stage_band(a, b, mode, ctx->num_cus, st));
+        } else {
+            HIP_TRY(ctx, launch_stage_up(a, u, mode, st));
+        }
     }
     return MULUT_OK;
 }
@@ -348,9 +392,20 @@ int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap) {
     return n;
 }
 
+int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
+    if (!ctx || !key) return MULUT_EINVAL;
+    if (!strcmp(key, "final_stage_kernel")) {
+        if (value < 0 || value > 2) return MULUT_EINVAL;
+        ctx->final_kernel = value;
+        return MULUT_OK;
+    }
+    return MULUT_EINVAL;
+}
+
 const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (!ctx || !ctx->configured) return "";
     if (!is_final || ctx->scale == 1) return stage_u1_name();
+    if (ctx->scale == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1) return stage_band_name(kOutPackedRGBU4);
     return stage_up_name(ctx->scale, ctx->scale == 4 ? kOutPackedRGBU4 : kOutGeneric);
 }
 

@@ -136,8 +136,13 @@ MULUT_HD int stage_bias_num(int n_modes, bool is_last) { return is_last ? 0 : 12
 template <int RW>
 MULUT_HD void swar_fma(uint32_t (&lo)[RW], uint32_t (&hi)[RW], const uint32_t (&row)[RW], uint32_t w) {
     for (int k = 0; k < RW; ++k) {
+#if defined(MULUT_ABLATE) && MULUT_ABLATE == 4   /* timing-only: no unpack (as if rows were u16 pairs) */
+        lo[k] += (row[k] & 0x00FFFFFFu) * w;
+        hi[k] += (row[k] >> 8) * w;
+#else
         lo[k] += (row[k] & 0x00FF00FFu) * w;
         hi[k] += ((row[k] >> 8) & 0x00FF00FFu) * w;
+#endif
     }
 }
 
@@ -167,6 +172,218 @@ MULUT_HD void static_for(F &&f) {
         f(IC<B>{});
         static_for<B + 1, E>(f);
     }
+}
+
+// ---- packed 2 x u16 helpers ------------------------------------------------------------------------
+// Two passes of one site are processed side by side in the low / high half of a dword.  On the
+// GPU these compile to v_pk_*_u16 (one instruction for both halves); the host versions exist for
+// tests/host_emul only.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned short mulut_u16x2 __attribute__((ext_vector_type(2)));
+#define MULUT_PK(x) __builtin_bit_cast(mulut_u16x2, (uint32_t)(x))
+#define MULUT_UNPK(v) __builtin_bit_cast(uint32_t, (v))
+MULUT_HD uint32_t pk_add(uint32_t a, uint32_t b) { return MULUT_UNPK(MULUT_PK(a) + MULUT_PK(b)); }
+MULUT_HD uint32_t pk_sub(uint32_t a, uint32_t b) { return MULUT_UNPK(MULUT_PK(a) - MULUT_PK(b)); }
+MULUT_HD uint32_t pk_min(uint32_t a, uint32_t b) { return MULUT_UNPK(__builtin_elementwise_min(MULUT_PK(a), MULUT_PK(b))); }
+MULUT_HD uint32_t pk_max(uint32_t a, uint32_t b) { return MULUT_UNPK(__builtin_elementwise_max(MULUT_PK(a), MULUT_PK(b))); }
+MULUT_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return MULUT_UNPK(MULUT_PK(a) * MULUT_PK(b) + MULUT_PK(c)); }
+MULUT_HD uint32_t pk_shr12(uint32_t a) { return MULUT_UNPK(MULUT_PK(a) >> (unsigned short)12); }
+#else
+MULUT_HD uint32_t pk_add(uint32_t a, uint32_t b) { return ((a + b) & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16); }
+MULUT_HD uint32_t pk_sub(uint32_t a, uint32_t b) { return ((a - b) & 0xFFFFu) | (((a >> 16) - (b >> 16)) << 16); }
+MULUT_HD uint32_t pk_min(uint32_t a, uint32_t b) {
+    const uint32_t l = (a & 0xFFFFu) < (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
+    const uint32_t h = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+    return l | (h << 16);
+}
+MULUT_HD uint32_t pk_max(uint32_t a, uint32_t b) {
+    const uint32_t l = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
+    const uint32_t h = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
+    return l | (h << 16);
+}
+MULUT_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
+    return (((a & 0xFFFFu) * (b & 0xFFFFu) + (c & 0xFFFFu)) & 0xFFFFu) | ((((a >> 16) * (b >> 16) + (c >> 16)) & 0xFFFFu) << 16);
+}
+MULUT_HD uint32_t pk_shr12(uint32_t a) { return ((a & 0xFFFFu) >> 12) | (((a >> 16) >> 12) << 16); }
+#endif
+MULUT_HD uint32_t pk_dup(uint32_t lo16) { return lo16 | (lo16 << 16); }
+MULUT_HD void pk_cmpx_desc(uint32_t &a, uint32_t &b) {
+    const uint32_t hi = pk_max(a, b), lo = pk_min(a, b);
+    a = hi;
+    b = lo;
+}
+
+// SWAR accumulate with the weight taken from one 16-bit half of a packed register (HALF = 0 low,
+// 1 high).  On the GPU this is one v_pk_mad_u16 per accumulator dword with op_sel picking the half for
+// both lanes -- no weight extraction and no separate add.  Fields never carry: value <= 255, w <= 16.
+template <int HALF>
+MULUT_HD uint32_t pk_mad_w(uint32_t x, uint32_t wpk, uint32_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const mulut_u16x2 wv = MULUT_PK(wpk);
+    const mulut_u16x2 ws = __builtin_shufflevector(wv, wv, HALF, HALF);
+    return MULUT_UNPK(MULUT_PK(x) * ws + MULUT_PK(acc));
+#else
+    const uint32_t w = HALF ? (wpk >> 16) : (wpk & 0xFFFFu);
+    return pk_mad(x, pk_dup(w), acc);
+#endif
+}
+template <int HALF>
+MULUT_HD void swar_fma4_pk(uint32_t (&lo)[4], uint32_t (&hi)[4], const uint32_t (&row)[4], uint32_t wpk) {
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = pk_mad_w<HALF>(row[k] & 0x00FF00FFu, wpk, lo[k]);
+        hi[k] = pk_mad_w<HALF>((row[k] >> 8) & 0x00FF00FFu, wpk, hi[k]);
+    }
+}
+
+// ---- diagonal band of a final-stage table (LDS-resident part) ---------------------------------------
+// Natural images keep the four keys of a patch within one MSB step of each other, so almost every
+// gather lands in the "band"  { (A,B,C,D) : B-A, C-A, D-A in [-2,2] }  of the 17^4 table: 17*125
+// rows (34 KB at 16 B/row) instead of 83521.  Band slot of a row:
+//      A*125 + (B-A+2)*25 + (C-A+2)*5 + (D-A+2)  =  A*94 + B*25 + C*5 + D + 62
+// i.e. fixed per-key strides (94, 25, 5, 1), so the simplex vertex walk works unchanged.  A pass is
+// "in band" iff |hb-ha|, |hc-ha|, |hd-ha| <= 1 (then all five vertices are); other passes take the
+// full table in global memory.
+constexpr int kBandSpan = 5;
+constexpr int kBandRowsPerA = kBandSpan * kBandSpan * kBandSpan;   // 125
+constexpr int kBandRows = kL * kBandRowsPerA;                      // 2125
+constexpr int kBandStrideA = kBandRowsPerA - 31, kBandStrideB = 25, kBandStrideC = 5, kBandStrideD = 1;
+constexpr int kBandBase = 62;
+MULUT_HD constexpr bool band_contains(int A, int B, int C, int D) {
+    return B - A >= -2 && B - A <= 2 && C - A >= -2 && C - A <= 2 && D - A >= -2 && D - A <= 2;
+}
+MULUT_HD constexpr int band_slot(int A, int B, int C, int D) {
+    return A * kBandStrideA + B * kBandStrideB + C * kBandStrideC + D * kBandStrideD + kBandBase;
+}
+
+// Two passes (low half = pass A, high half = pass B) of one site against a band table with 16-byte
+// rows.  va: anchor value (shared); pb/pc/pd: key values of both passes packed (vA | vB << 16).
+// Outputs, packed per pass: byte offsets addr[5] of the five rows inside the band image, weights
+// w[5], and t_band (<= 32 in a half  <=>  that pass is in band).
+struct BandPair {
+    uint32_t addr[5];
+    uint32_t w[5];
+    uint32_t t_band;
+};
+MULUT_HD void simplex4_band_pair(uint32_t va, uint32_t pb, uint32_t pc, uint32_t pd, BandPair &o) {
+    constexpr uint32_t RB = 16;  // row bytes
+    constexpr uint32_t SA = kBandStrideA * RB, SB = kBandStrideB * RB, SC = kBandStrideC * RB, SD = kBandStrideD * RB;
+    const uint32_t hb16 = pb & 0x00F000F0u, hc16 = pc & 0x00F000F0u, hd16 = pd & 0x00F000F0u;  // 16*h per half
+    const uint32_t ha16 = va & 0xF0u;
+    // keys: f << 12 | byte stride (< 4096), sorted descending per half by a 5-comparator network
+    uint32_t k0 = pk_dup(((va & 15u) << 12) | SA);
+    uint32_t k1 = ((pb << 12) & 0xF000F000u) | pk_dup(SB);
+    uint32_t k2 = ((pc << 12) & 0xF000F000u) | pk_dup(SC);
+    uint32_t k3 = ((pd << 12) & 0xF000F000u) | pk_dup(SD);
+    pk_cmpx_desc(k0, k1);
+    pk_cmpx_desc(k2, k3);
+    pk_cmpx_desc(k0, k2);
+    pk_cmpx_desc(k1, k3);
+    pk_cmpx_desc(k1, k2);
+    const uint32_t f1 = pk_shr12(k0), f2 = pk_shr12(k1), f3 = pk_shr12(k2), f4 = pk_shr12(k3);
+    // base byte offset: (ha*94 + hb*25 + hc*5 + hd + 62) * 16, built from the 16*h nibbles
+    const uint32_t base_a = pk_dup((ha16 * kBandStrideA) + kBandBase * RB);
+    const uint32_t base = pk_mad(hb16, pk_dup(kBandStrideB), pk_mad(hc16, pk_dup(kBandStrideC), pk_add(hd16, base_a)));
+    o.addr[0] = base;
+    o.addr[1] = pk_add(base, k0 & 0x0FFF0FFFu);
+    o.addr[2] = pk_add(o.addr[1], k1 & 0x0FFF0FFFu);
+    o.addr[3] = pk_add(o.addr[2], k2 & 0x0FFF0FFFu);
+    o.addr[4] = pk_add(base, pk_dup(kBandRowsPerA * RB));
+    o.w[0] = pk_sub(pk_dup(kQ), f1);
+    o.w[1] = pk_sub(f1, f2);
+    o.w[2] = pk_sub(f2, f3);
+    o.w[3] = pk_sub(f3, f4);
+    o.w[4] = f4;
+    // in band <=> 16*(h - ha + 1) in {0,16,32} for b, c, d (out-of-range differences wrap to >= 0xFFF0 or reach 48+)
+    const uint32_t off = pk_dup((16u - ha16) & 0xFFFFu);
+    o.t_band = pk_max(pk_max(pk_add(hb16, off), pk_add(hc16, off)), pk_add(hd16, off));
+}
+
+// ---- merged rotation pairs ----------------------------------------------------------------------------
+// Rotation r+2 maps row element e to the block position that rotation r gives element 15-e
+// (row_elem(r+2,sy,sx,4) == 15 - row_elem(r,sy,sx,4)), so the rows of rotation r+2 can be added
+// into rotation r's accumulator in reversed element order: 8 accumulator dwords per pair instead
+// of 16.  In the SWAR layout reversal sends dword k' -> 3-k', swaps lo <-> hi and swaps the two
+// 16-bit fields; the byte shuffles below (one v_perm_b32 each on the GPU) produce the swapped
+// fields directly.
+MULUT_HD uint32_t bytes_3_1(uint32_t x) {  // (b3, 0, b1, 0): fields (elem 3, elem 1) of the dword
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0u, x, 0x0C010C03u);
+#else
+    return (x >> 24) | (((x >> 8) & 0xFFu) << 16);
+#endif
+}
+MULUT_HD uint32_t bytes_2_0(uint32_t x) {  // (b2, 0, b0, 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0u, x, 0x0C000C02u);
+#else
+    return ((x >> 16) & 0xFFu) | ((x & 0xFFu) << 16);
+#endif
+}
+MULUT_HD void swar_fma_rev4(uint32_t (&lo)[4], uint32_t (&hi)[4], const uint32_t (&row)[4], uint32_t w) {
+    for (int k = 0; k < 4; ++k) {
+        lo[3 - k] += bytes_3_1(row[k]) * w;   // elems (4k+3, 4k+1) -> reversed (4(3-k)+0, 4(3-k)+2)
+        hi[3 - k] += bytes_2_0(row[k]) * w;   // elems (4k+2, 4k+0) -> reversed (4(3-k)+1, 4(3-k)+3)
+    }
+}
+
+template <int HALF>
+MULUT_HD void swar_fma_rev4_pk(uint32_t (&lo)[4], uint32_t (&hi)[4], const uint32_t (&row)[4], uint32_t wpk) {
+    for (int k = 0; k < 4; ++k) {
+        lo[3 - k] = pk_mad_w<HALF>(bytes_3_1(row[k]), wpk, lo[3 - k]);
+        hi[3 - k] = pk_mad_w<HALF>(bytes_2_0(row[k]), wpk, hi[3 - k]);
+    }
+}
+
+// Sum of both pair accumulators in output order (u = 4): S[e0] = acc02[e0] + acc13[e1] with
+// e0 = 4*sy+sx (rotation-0 layout == block layout) and e1 = (3-sx)*4 + sy (rotation-1 layout).
+MULUT_HD void combine_pairs4(const uint32_t (&lo02)[4], const uint32_t (&hi02)[4], const uint32_t (&lo13)[4],
+                             const uint32_t (&hi13)[4], uint32_t (&lo)[4], uint32_t (&hi)[4]) {
+    // out dword sy, position sx  <-  acc13 dword 3-sx, position sy
+    //   positions 0,2 live in lo[], 1,3 in hi[]; positions 0,1 are the low 16 bits, 2,3 the high 16
+    lo[0] = lo02[0] + ((lo13[3] & 0xFFFFu) | (lo13[1] << 16));
+    hi[0] = hi02[0] + ((lo13[2] & 0xFFFFu) | (lo13[0] << 16));
+    lo[1] = lo02[1] + ((hi13[3] & 0xFFFFu) | (hi13[1] << 16));
+    hi[1] = hi02[1] + ((hi13[2] & 0xFFFFu) | (hi13[0] << 16));
+    lo[2] = lo02[2] + ((lo13[3] >> 16) | (lo13[1] & 0xFFFF0000u));
+    hi[2] = hi02[2] + ((lo13[2] >> 16) | (lo13[0] & 0xFFFF0000u));
+    lo[3] = lo02[3] + ((hi13[3] >> 16) | (hi13[1] & 0xFFFF0000u));
+    hi[3] = hi02[3] + ((hi13[2] >> 16) | (hi13[0] & 0xFFFF0000u));
+}
+
+// ---- float form of the epilogue -------------------------------------------------------------------------
+// clip(rhe(K/d)) as  cvt -> mul by fl(1/d) -> round-to-nearest-even -> saturating u8 convert.  It is
+// exact iff K*fl(1/d) rounds to the exact tie value whenever K/d is a tie; rhe_f32_valid() checks that
+// by brute force over the whole numerator range at configure time (it holds for d = 16*M, 64*M with
+// M in 1..6 and 8), otherwise the integer form is used.
+MULUT_HD uint32_t rhe_clip_u8_f32(int K, float inv_d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float q = __builtin_rintf((float)K * inv_d);
+    return __builtin_amdgcn_cvt_pk_u8_f32(q, 0u, 0u);
+#else
+    const float q = __builtin_rintf((float)K * inv_d);
+    return q < 0.0f ? 0u : (q > 255.0f ? 255u : (uint32_t)q);
+#endif
+}
+
+// four results packed into one dword (byte i = clip(rhe(K_i / d))): one v_cvt_pk_u8_f32 per byte on the GPU
+MULUT_HD uint32_t rhe_pack4_f32(int K0, int K1, int K2, int K3, float inv_d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf((float)K0 * inv_d), 0u, 0u);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf((float)K1 * inv_d), 1u, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf((float)K2 * inv_d), 2u, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf((float)K3 * inv_d), 3u, r);
+    return r;
+#else
+    return rhe_clip_u8_f32(K0, inv_d) | (rhe_clip_u8_f32(K1, inv_d) << 8) | (rhe_clip_u8_f32(K2, inv_d) << 16) |
+           (rhe_clip_u8_f32(K3, inv_d) << 24);
+#endif
+}
+
+// brute-force proof that the float epilogue equals the integer one for every numerator in [kmin, kmax]
+MULUT_HD bool rhe_f32_valid(int kmin, int kmax, DivMagic m, float inv_d) {
+    for (int k = kmin; k <= kmax; ++k)
+        if (rhe_clip_u8_f32(k, inv_d) != rhe_clip_u8(k, m)) return false;
+    return true;
 }
 
 }  // namespace mulut

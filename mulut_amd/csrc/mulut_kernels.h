@@ -34,9 +34,12 @@ struct StageArgs {
     int tiles_x, tiles_y;   // tile grid over [oy0,oy1) x [0,W)
     int M;                  // number of modes
     const void *lut[kMaxModes];
-    signed char di[kMaxModes][3], dj[kMaxModes][3];  // pattern offsets of keys b,c,d (rotation 0)
+    int di[kMaxModes][3], dj[kMaxModes][3];  // pattern offsets of keys b,c,d (rotation 0); dwords so that
+                                             // a runtime mode index is served by scalar loads
     DivMagic div;           // epilogue divisor (16*M final, 64*M non-final)
     int bias_num;           // numerator bias (127*64*M non-final, 0 final)
+    float inv_d;            // fl(1/d) for the float epilogue
+    int use_f32;            // float epilogue proven exact for this divisor (rhe_f32_valid)
 };
 
 struct PassArgs {
@@ -47,6 +50,10 @@ struct PassArgs {
     signed char di[3], dj[3];
 };
 
+struct BandArgs {
+    const void *band[3];   // device images of the diagonal band of each mode's table (kBandRows x 16 B)
+};
+
 enum K2Out { kOutGeneric = 0, kOutPlanarU4 = 1, kOutPackedRGBU4 = 2 };
 
 hipError_t launch_pass(const PassArgs &a, hipStream_t st);
@@ -54,6 +61,10 @@ hipError_t launch_pass(const PassArgs &a, hipStream_t st);
 hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st);
 // final stage with u in {2,3,4}: u*u bytes out per site
 hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t st);
+// final stage, u == 4, M <= 3: band tables resident in LDS, persistent workgroups
+hipError_t launch_stage_band(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
+void stage_band_tile(int &tw, int &th);
+const char *stage_band_name(int out_mode);
 void stage_u1_tile(int &tw, int &th);
 void stage_up_tile(int &tw, int &th);
 const char *stage_u1_name();

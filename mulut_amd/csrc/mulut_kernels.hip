@@ -17,6 +17,7 @@
 // MULUT_ABLATE selects timing-only variants (wrong results!) built by tools/ab_bench.py into
 // build/ablate/; the shipped library is always built with MULUT_ABLATE == 0.
 //   K2:  1 every row gather reads row 0   2 no gathers (rows synthesised)   3 gathers, no SWAR fma
+//   K2:  4 SWAR fma without the byte unpack    5 epilogue without divide/round/clip
 //   K1: 11 every LUT read hits byte 0     12 no LUT reads                   13 no table staging
 #ifndef MULUT_ABLATE
 #define MULUT_ABLATE 0
@@ -106,8 +107,8 @@ __device__ __forceinline__ void load_tile(const StageArgs &a, int n, int y0, int
     }
 }
 
-__device__ __forceinline__ void decode_tile(const StageArgs &a, int &n, int &y0, int &x0, int TW, int TH) {
-    int b = blockIdx.x;
+__device__ __forceinline__ void decode_tile(const StageArgs &a, int tile, int &n, int &y0, int &x0, int TW, int TH) {
+    int b = tile;
     const int tx = b % a.tiles_x;
     b /= a.tiles_x;
     const int ty = b % a.tiles_y;
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(NT) stage_u1_kernel(StageArgs a) {
     uint8_t *s_img = smem + kU1TableBytes;
 
     int n, y0, x0;
-    decode_tile(a, n, y0, x0, TW, TH);
+    decode_tile(a, blockIdx.x, n, y0, x0, TW, TH);
     load_tile<TW, TH, NT>(a, n, y0, x0, s_img);
 
     const int nsamp = a.C * TH * TW;
@@ -226,50 +227,215 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: final stage, u*u-byte rows gathered from the L2-resident tables.
-// One thread = one LR pixel, channels in sequence.  Per rotation the 15 (= M*5) weighted rows are
+// K2: final stage, u*u-byte rows.
+// One thread = one LR pixel, channels in sequence.  Per rotation the 5*M weighted rows are
 // accumulated as 16-bit fields, two per dword:  lo[k] holds row elements 4k and 4k+2, hi[k] holds
 // 4k+1 and 4k+3 (each table byte is value+128, so every field stays non-negative:
-// 4 rot * M * 16 * 255 < 65536 for M <= 4).
+// M * 16 * 255 < 65536 per rotation for M <= 16).
+//   stage_up_kernel    generic (u in {2,3,4}, any M): every row is gathered from the full table in
+//                      global memory (L1/L2); TA-bound at ~38 cycles per gather instruction per CU.
+//   stage_band_kernel  u == 4, M <= 3: the diagonal band of each table (mulut_core.h) is resident in
+//                      LDS for the lifetime of a persistent workgroup; in-band passes gather with
+//                      ds_read_b128, the rest fall back to the full table.  Two passes (rotations r
+//                      and r+2) run side by side in packed 16-bit halves.
 // ------------------------------------------------------------------------------------------
 template <int U>
 __device__ __forceinline__ void load_row(const void *lut, int idx, uint32_t (&row)[row_dwords(U)]) {
     constexpr int RW = row_dwords(U);
     if constexpr (RW == 4) {
-        const uint4 v = ((const uint4 *)lut)[idx];
+        const uint4 v = *(const uint4 *)((const char *)lut + ((uint32_t)idx << 4));
         row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
     } else {
-        const uint32_t *p = (const uint32_t *)lut + (long long)idx * RW;
+        const uint32_t *p = (const uint32_t *)lut + (uint32_t)idx * RW;
 #pragma unroll
         for (int k = 0; k < RW; ++k) row[k] = p[k];
     }
 }
 
+// Per-rotation SWAR accumulators with compile-time names.  u == 4 merges rotation pairs (r, r+2)
+// into one accumulator each (mulut_core.h "merged rotation pairs"): 16 VGPRs instead of 32.
+template <int U>
+struct RotAcc {
+    static constexpr int RW = row_dwords(U);
+    uint32_t lo0[RW], hi0[RW], lo1[RW], hi1[RW], lo2[RW], hi2[RW], lo3[RW], hi3[RW];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < RW; ++k) lo0[k] = hi0[k] = lo1[k] = hi1[k] = lo2[k] = hi2[k] = lo3[k] = hi3[k] = 0;
+    }
+    template <int R>
+    __device__ __forceinline__ void fma(const uint32_t (&row)[RW], uint32_t w) {
+        if constexpr (R == 0) swar_fma<RW>(lo0, hi0, row, w);
+        if constexpr (R == 1) swar_fma<RW>(lo1, hi1, row, w);
+        if constexpr (R == 2) swar_fma<RW>(lo2, hi2, row, w);
+        if constexpr (R == 3) swar_fma<RW>(lo3, hi3, row, w);
+    }
+    // field sum of block position (sy, sx) over the four rotations
+    template <int SY, int SX>
+    __device__ __forceinline__ uint32_t sum() const {
+        return swar_field<row_elem(0, SY, SX, U), RW>(lo0, hi0) + swar_field<row_elem(1, SY, SX, U), RW>(lo1, hi1) +
+               swar_field<row_elem(2, SY, SX, U), RW>(lo2, hi2) + swar_field<row_elem(3, SY, SX, U), RW>(lo3, hi3);
+    }
+    __device__ __forceinline__ void finalize() {}
+};
+
+template <>
+struct RotAcc<4> {
+    static constexpr int RW = 4;
+    uint32_t lo02[4], hi02[4], lo13[4], hi13[4];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lo02[k] = hi02[k] = lo13[k] = hi13[k] = 0;
+    }
+    template <int R>
+    __device__ __forceinline__ void fma(const uint32_t (&row)[4], uint32_t w) {
+        if constexpr (R == 0) swar_fma<4>(lo02, hi02, row, w);
+        if constexpr (R == 1) swar_fma<4>(lo13, hi13, row, w);
+        if constexpr (R == 2) swar_fma_rev4(lo02, hi02, row, w);
+        if constexpr (R == 3) swar_fma_rev4(lo13, hi13, row, w);
+    }
+    // weight = 16-bit half HALF of a packed register (band kernel): one v_pk_mad_u16 per dword
+    template <int R, int HALF>
+    __device__ __forceinline__ void fma_pk(const uint32_t (&row)[4], uint32_t wpk) {
+        if constexpr (R == 0) swar_fma4_pk<HALF>(lo02, hi02, row, wpk);
+        if constexpr (R == 1) swar_fma4_pk<HALF>(lo13, hi13, row, wpk);
+        if constexpr (R == 2) swar_fma_rev4_pk<HALF>(lo02, hi02, row, wpk);
+        if constexpr (R == 3) swar_fma_rev4_pk<HALF>(lo13, hi13, row, wpk);
+    }
+    // after finalize(): lo02/hi02 hold the sum of all four rotations in block order
+    __device__ __forceinline__ void finalize() {
+        uint32_t lo[4], hi[4];
+        combine_pairs4(lo02, hi02, lo13, hi13, lo, hi);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lo02[k] = lo[k]; hi02[k] = hi[k]; }
+    }
+    template <int SY, int SX>
+    __device__ __forceinline__ uint32_t sum() const {
+        const uint32_t word = (SX & 1) ? hi02[SY] : lo02[SY];
+        return (SX & 2) ? (word >> 16) : (word & 0xFFFFu);
+    }
+};
+
+// rotate back + sum the four rotations, remove the +128 bias, divide / round-half-even / clip, and
+// either store (planar / generic) or hand the packed rows to the RGB interleave.
+template <int U, int OUT>
+__device__ __forceinline__ void finish_channel(const StageArgs &a, RotAcc<U> &acc, int n, int c, int y, int x,
+                                               uint32_t (&o)[U]) {
+    const int unbias = 128 * kQ * 4 * a.M - a.bias_num;
+    acc.finalize();
+    static_for<0, U>([&](auto SY) {
+        constexpr int sy = SY;
+        uint32_t packed = 0;
+        if constexpr (U == 4 && OUT != kOutGeneric) {
+            const int k0 = (int)acc.template sum<sy, 0>() - unbias, k1 = (int)acc.template sum<sy, 1>() - unbias;
+            const int k2 = (int)acc.template sum<sy, 2>() - unbias, k3 = (int)acc.template sum<sy, 3>() - unbias;
+#if MULUT_ABLATE == 5   /* timing-only: no divide / round / clip */
+            packed = (uint32_t)(k0 ^ k1 ^ k2 ^ k3);
+#else
+            if (a.use_f32)   // wave-uniform
+                packed = rhe_pack4_f32(k0, k1, k2, k3, a.inv_d);
+            else
+                packed = rhe_clip_u8(k0, a.div) | (rhe_clip_u8(k1, a.div) << 8) | (rhe_clip_u8(k2, a.div) << 16) |
+                         (rhe_clip_u8(k3, a.div) << 24);
+#endif
+        } else {
+            static_for<0, U>([&](auto SX) {
+                constexpr int sx = SX;
+                const uint32_t v = rhe_clip_u8((int)acc.template sum<sy, sx>() - unbias, a.div);
+                if constexpr (OUT == kOutGeneric) {
+                    *const_cast<uint8_t *>(view_addr(a.out, n, c, y * U + sy, x * U + sx)) = (uint8_t)v;
+                } else {
+                    packed |= v << (8 * sx);
+                }
+            });
+        }
+        o[sy] = packed;
+        if constexpr (OUT == kOutPlanarU4) {
+            *(uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n, c, y * U + sy, x * U)) = packed;
+        }
+    });
+}
+
+template <int U>
+__device__ __forceinline__ void store_rgb(const StageArgs &a, int n, int y, int x, const uint32_t (&oR)[U],
+                                          const uint32_t (&oG)[U], const uint32_t (&oB)[U]) {
+#pragma unroll
+    for (int sy = 0; sy < U; ++sy) {
+        uint32_t w0, w1, w2;
+        interleave_rgb4(oR[sy], oG[sy], oB[sy], w0, w1, w2);
+        uint32_t *dst = (uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n, 0, y * U + sy, x * U));
+        dst[0] = w0;
+        dst[1] = w1;
+        dst[2] = w2;
+    }
+}
+
+// keeps the channel's packed rows in named registers (c is wave-uniform -> scalar branches)
+template <int U>
+__device__ __forceinline__ void keep_rgb(int c, const uint32_t (&o)[U], uint32_t (&oR)[U], uint32_t (&oG)[U],
+                                         uint32_t (&oB)[U]) {
+    if (c == 0) {
+#pragma unroll
+        for (int sy = 0; sy < U; ++sy) oR[sy] = o[sy];
+    } else if (c == 1) {
+#pragma unroll
+        for (int sy = 0; sy < U; ++sy) oG[sy] = o[sy];
+    } else {
+#pragma unroll
+        for (int sy = 0; sy < U; ++sy) oB[sy] = o[sy];
+    }
+}
+
+// one pass against the full table in global memory
+template <int U, int R>
+__device__ __forceinline__ void pass_global(const void *lut, int va, int vb, int vc, int vd, const StageArgs &a,
+                                            RotAcc<U> &acc) {
+    constexpr int RW = row_dwords(U);
+    int idx[5], w[5];
+    simplex4(va, vb, vc, vd, idx, w);
+    uint32_t row[5][RW];
+#if MULUT_ABLATE == 1
+#pragma unroll
+    for (int j = 0; j < 5; ++j) idx[j] &= (a.N >> 30);
+#endif
+#if MULUT_ABLATE == 2
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int k = 0; k < RW; ++k) row[j][k] = (uint32_t)idx[j] + k;
+#else
+#pragma unroll
+    for (int j = 0; j < 5; ++j) load_row<U>(lut, idx[j], row[j]);
+#endif
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc.template fma<R>(row[j], (uint32_t)w[j]);
+}
+
 template <int U, int OUT, int TW, int TH>
-__global__ void __launch_bounds__(TW *TH) stage_up_kernel(StageArgs a) {
+__global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
     constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
     constexpr int NT = TW * TH;
-    constexpr int RW = row_dwords(U);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_img = smem;
 
     int n, y0, x0;
-    decode_tile(a, n, y0, x0, TW, TH);
+    decode_tile(a, blockIdx.x, n, y0, x0, TW, TH);
     load_tile<TW, TH, NT>(a, n, y0, x0, s_img);
     __syncthreads();
 
     const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
     const int y = y0 + ty, x = x0 + tx;
     if (y >= a.oy1 || x >= a.W) return;
-    // packed-RGB path keeps the three channels' rows in named registers until the interleave
+
     uint32_t oR[U], oG[U], oB[U];
     for (int c = 0; c < a.C; ++c) {
         const uint8_t *ctr = s_img + c * (PH * PW) + (ty + kHalo) * PW + (tx + kHalo);
         const int va = ctr[0];
-        uint32_t lo0[RW], hi0[RW], lo1[RW], hi1[RW], lo2[RW], hi2[RW], lo3[RW], hi3[RW];
-#pragma unroll
-        for (int k = 0; k < RW; ++k) lo0[k] = hi0[k] = lo1[k] = hi1[k] = lo2[k] = hi2[k] = lo3[k] = hi3[k] = 0;
-        for (int m = 0; m < a.M; ++m) {
+        RotAcc<U> acc;
+        acc.clear();
+        for (int mv = 0; mv < a.M; ++mv) {
+            // the mode index is wave-uniform: pin it to an SGPR so the per-mode kernel arguments
+            // (table pointer, pattern offsets) are fetched with scalar loads, not per-lane VMEM
+            const int m = __builtin_amdgcn_readfirstlane(mv);
             const void *lut = a.lut[m];
             const int di0 = a.di[m][0], di1 = a.di[m][1], di2 = a.di[m][2];
             const int dj0 = a.dj[m][0], dj1 = a.dj[m][1], dj2 = a.dj[m][2];
@@ -279,93 +445,14 @@ __global__ void __launch_bounds__(TW *TH) stage_up_kernel(StageArgs a) {
                 sample_offset(r, di0, dj0, dy, dx); v0 = ctr[dy * PW + dx];
                 sample_offset(r, di1, dj1, dy, dx); v1 = ctr[dy * PW + dx];
                 sample_offset(r, di2, dj2, dy, dx); v2 = ctr[dy * PW + dx];
-                int idx[5], w[5];
-                simplex4(va, v0, v1, v2, idx, w);
-                uint32_t row[5][RW];
-#if MULUT_ABLATE == 1
-#pragma unroll
-                for (int j = 0; j < 5; ++j) idx[j] &= (a.N >> 30);
-#endif
-#if MULUT_ABLATE == 2
-#pragma unroll
-                for (int j = 0; j < 5; ++j)
-#pragma unroll
-                    for (int k = 0; k < RW; ++k) row[j][k] = (uint32_t)idx[j] + k;
-#else
-#pragma unroll
-                for (int j = 0; j < 5; ++j) load_row<U>(lut, idx[j], row[j]);
-#endif
-#if MULUT_ABLATE == 3
-#pragma unroll
-                for (int j = 0; j < 5; ++j)
-#pragma unroll
-                    for (int k = 0; k < RW; ++k) {
-                        if constexpr (r == 0) lo0[k] ^= row[j][k] + w[j];
-                        if constexpr (r == 1) lo1[k] ^= row[j][k] + w[j];
-                        if constexpr (r == 2) lo2[k] ^= row[j][k] + w[j];
-                        if constexpr (r == 3) lo3[k] ^= row[j][k] + w[j];
-                    }
-#else
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    if constexpr (r == 0) swar_fma<RW>(lo0, hi0, row[j], (uint32_t)w[j]);
-                    if constexpr (r == 1) swar_fma<RW>(lo1, hi1, row[j], (uint32_t)w[j]);
-                    if constexpr (r == 2) swar_fma<RW>(lo2, hi2, row[j], (uint32_t)w[j]);
-                    if constexpr (r == 3) swar_fma<RW>(lo3, hi3, row[j], (uint32_t)w[j]);
-                }
-#endif
+                pass_global<U, r>(lut, va, v0, v1, v2, a, acc);
             });
         }
-        // rotate back + sum the four rotations, remove the +128 bias, divide/round/clip
-        const int unbias = 128 * kQ * 4 * a.M;
         uint32_t o[U];
-        static_for<0, U>([&](auto SY) {
-            constexpr int sy = SY;
-            uint32_t packed = 0;
-            static_for<0, U>([&](auto SX) {
-                constexpr int sx = SX;
-                const uint32_t sum = swar_field<row_elem(0, sy, sx, U), RW>(lo0, hi0) +
-                                     swar_field<row_elem(1, sy, sx, U), RW>(lo1, hi1) +
-                                     swar_field<row_elem(2, sy, sx, U), RW>(lo2, hi2) +
-                                     swar_field<row_elem(3, sy, sx, U), RW>(lo3, hi3);
-                const uint32_t v = rhe_clip_u8((int)sum - unbias + a.bias_num, a.div);
-                if constexpr (OUT == kOutGeneric) {
-                    *const_cast<uint8_t *>(view_addr(a.out, n, c, y * U + sy, x * U + sx)) = (uint8_t)v;
-                } else {
-                    packed |= v << (8 * sx);
-                }
-            });
-            o[sy] = packed;
-            if constexpr (OUT == kOutPlanarU4) {
-                *(uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n, c, y * U + sy, x * U)) = packed;
-            }
-        });
-        if constexpr (OUT == kOutPackedRGBU4) {  // c is wave-uniform: scalar branches, static register names
-            if (c == 0) {
-#pragma unroll
-                for (int sy = 0; sy < U; ++sy) oR[sy] = o[sy];
-            } else if (c == 1) {
-#pragma unroll
-                for (int sy = 0; sy < U; ++sy) oG[sy] = o[sy];
-            } else {
-#pragma unroll
-                for (int sy = 0; sy < U; ++sy) oB[sy] = o[sy];
-            }
-        }
+        finish_channel<U, OUT>(a, acc, n, c, y, x, o);
+        if constexpr (OUT == kOutPackedRGBU4) keep_rgb<U>(c, o, oR, oG, oB);
     }
-    if constexpr (OUT == kOutPackedRGBU4) {
-        // [r0 r1 r2 r3],[g0..g3],[b0..b3] -> r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3 (12 bytes per HR row)
-#pragma unroll
-        for (int sy = 0; sy < U; ++sy) {
-            const uint32_t R = oR[sy], G = oG[sy], B = oB[sy];
-            uint32_t w0, w1, w2;
-            interleave_rgb4(R, G, B, w0, w1, w2);
-            uint32_t *dst = (uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n, 0, y * U + sy, x * U));
-            dst[0] = w0;
-            dst[1] = w1;
-            dst[2] = w2;
-        }
-    }
+    if constexpr (OUT == kOutPackedRGBU4) store_rgb<U>(a, n, y, x, oR, oG, oB);
 }
 
 constexpr int K2_TW = 32, K2_TH = 8;
@@ -399,6 +486,125 @@ hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t 
         case 4: return launch_up<4, kOutGeneric>(a, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2-band: persistent workgroups, band tables resident in LDS
+// LDS: [ band of mode 0 | band of mode 1 | band of mode 2 : 34000 B each ][ image tile ]
+// ------------------------------------------------------------------------------------------
+constexpr int kBandBytes = kBandRows * 16;
+static_assert(kBandBytes % 16 == 0, "band image must keep 16-byte alignment");
+
+// one pass of a pair: low (HALF == 0) or high (HALF == 1) 16-bit half of the packed results
+template <int R, int HALF>
+__device__ __forceinline__ void pass_band(const uint8_t *band, const void *lut, const BandPair &bp, int va, int vb,
+                                          int vc, int vd, const StageArgs &a, RotAcc<4> &acc) {
+    const uint32_t t = HALF ? (bp.t_band >> 16) : (bp.t_band & 0xFFFFu);
+    if (t <= 32u) {
+        uint32_t row[5][4];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t off = HALF ? (bp.addr[j] >> 16) : (bp.addr[j] & 0xFFFFu);
+            const uint4 v = *(const uint4 *)(band + off);
+            row[j][0] = v.x; row[j][1] = v.y; row[j][2] = v.z; row[j][3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc.template fma_pk<R, HALF>(row[j], bp.w[j]);
+    } else {
+        pass_global<4, R>(lut, va, vb, vc, vd, a, acc);
+    }
+}
+
+template <int OUT, int TW, int TH>
+__global__ void __launch_bounds__(TW *TH) stage_band_kernel(StageArgs a, BandArgs b) {
+    constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
+    constexpr int NT = TW * TH;
+    constexpr int U = 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *s_band = smem;
+    uint8_t *s_img = smem + a.M * kBandBytes;
+
+    for (int m = 0; m < a.M; ++m) {
+        const uint4 *src = (const uint4 *)b.band[m];
+        uint4 *dst = (uint4 *)(s_band + m * kBandBytes);
+        for (int i = threadIdx.x; i < kBandBytes / 16; i += NT) dst[i] = src[i];
+    }
+    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int n, y0, x0;
+        decode_tile(a, tile, n, y0, x0, TW, TH);
+        __syncthreads();  // band staged (first trip) / everyone done reading the previous tile
+        load_tile<TW, TH, NT>(a, n, y0, x0, s_img);
+        __syncthreads();
+        const int y = y0 + ty, x = x0 + tx;
+        if (y >= a.oy1 || x >= a.W) continue;   // no barrier below this point inside the trip
+
+        uint32_t oR[U], oG[U], oB[U];
+        for (int c = 0; c < a.C; ++c) {
+            const uint8_t *ctr = s_img + c * (PH * PW) + (ty + kHalo) * PW + (tx + kHalo);
+            const int va = ctr[0];
+            RotAcc<4> acc;
+            acc.clear();
+            for (int mv = 0; mv < a.M; ++mv) {
+                const int m = __builtin_amdgcn_readfirstlane(mv);   // SGPR: scalar loads of the per-mode arguments
+                const uint8_t *band = s_band + m * kBandBytes;
+                const void *lut = a.lut[m];
+                const int di0 = a.di[m][0], di1 = a.di[m][1], di2 = a.di[m][2];
+                const int dj0 = a.dj[m][0], dj1 = a.dj[m][1], dj2 = a.dj[m][2];
+                static_for<0, 2>([&](auto P) {
+                    constexpr int r = P;          // pair (r, r + 2): opposite sampling offsets
+                    int dy, dx;
+                    sample_offset(r, di0, dj0, dy, dx); const int o0 = dy * PW + dx;
+                    sample_offset(r, di1, dj1, dy, dx); const int o1 = dy * PW + dx;
+                    sample_offset(r, di2, dj2, dy, dx); const int o2 = dy * PW + dx;
+                    const int b0 = ctr[o0], b1 = ctr[-o0], c0 = ctr[o1], c1 = ctr[-o1], d0 = ctr[o2], d1 = ctr[-o2];
+                    BandPair bp;
+                    simplex4_band_pair((uint32_t)va, (uint32_t)b0 | ((uint32_t)b1 << 16), (uint32_t)c0 | ((uint32_t)c1 << 16),
+                                       (uint32_t)d0 | ((uint32_t)d1 << 16), bp);
+                    pass_band<r, 0>(band, lut, bp, va, b0, c0, d0, a, acc);
+                    pass_band<r + 2, 1>(band, lut, bp, va, b1, c1, d1, a, acc);
+                });
+            }
+            uint32_t o[U];
+            finish_channel<U, OUT>(a, acc, n, c, y, x, o);
+            if constexpr (OUT == kOutPackedRGBU4) keep_rgb<U>(c, o, oR, oG, oB);
+        }
+        if constexpr (OUT == kOutPackedRGBU4) store_rgb<U>(a, n, y, x, oR, oG, oB);
+    }
+}
+
+constexpr int KB_TW = 64, KB_TH = 16;
+void stage_band_tile(int &tw, int &th) { tw = KB_TW; th = KB_TH; }
+const char *stage_band_name(int out_mode) {
+    return out_mode == kOutPackedRGBU4 ? "stage_band_kernel<rgb>" : out_mode == kOutPlanarU4 ? "stage_band_kernel<planar>"
+                                                                                               : "stage_band_kernel<generic>";
+}
+
+template <int OUT>
+static hipError_t launch_band_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
+    auto kern = stage_band_kernel<OUT, KB_TW, KB_TH>;
+    const size_t lds = (size_t)a.M * kBandBytes + (size_t)a.C * (KB_TH + 2 * kHalo) * (KB_TW + 2 * kHalo);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
+    if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(ntiles < num_cus ? ntiles : num_cus);   // one persistent workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(KB_TW * KB_TH), lds, st, a, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_band(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st) {
+    if (a.C > 3 || a.M > 3) return hipErrorInvalidValue;
+    if (out_mode == kOutPlanarU4) return launch_band_t<kOutPlanarU4>(a, b, num_cus, st);
+    if (out_mode == kOutPackedRGBU4 && a.C == 3) return launch_band_t<kOutPackedRGBU4>(a, b, num_cus, st);
+    return launch_band_t<kOutGeneric>(a, b, num_cus, st);
 }
 
 }  // namespace mulut

@@ -178,3 +178,8 @@ class MuLUTEngine:
         if n < 0:
             self._check(n)
         return [float(buf[k]) for k in range(n)]
+
+    def set_tuning(self, key, value):
+        """Performance knobs that never change results, e.g. ("final_stage_kernel", 1)."""
+        self._check(self._lib.mulut_set_tuning(self._h, key.encode(), int(value)))
+        return self

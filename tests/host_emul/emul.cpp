@@ -35,6 +35,7 @@ static void stage_up(const int8_t *const *luts, const char *modes, int M, const 
                 const uint8_t *pl = in + (size_t)c * H * W;  // planar input
                 const int va = pl[(size_t)y * W + x];
                 uint32_t lo[4][RW] = {}, hi[4][RW] = {};
+                uint32_t lo02[4] = {}, hi02[4] = {}, lo13[4] = {}, hi13[4] = {};   // u == 4: merged rotation pairs
                 for (int m = 0; m < M; ++m) {
                     int di[3], dj[3];
                     pattern_offsets(modes[m], di, dj);
@@ -50,24 +51,46 @@ static void stage_up(const int8_t *const *luts, const char *modes, int M, const 
                         for (int j = 0; j < 5; ++j) {
                             uint32_t row[RW];
                             for (int k = 0; k < RW; ++k) row[k] = tabs[m][(size_t)idx[j] * RW + k];
-                            swar_fma<RW>(lo[r], hi[r], row, (uint32_t)w[j]);
+                            if constexpr (U == 4) {
+                                uint32_t(&row4)[4] = reinterpret_cast<uint32_t(&)[4]>(row);
+                                if (r == 0) swar_fma<4>(lo02, hi02, row4, (uint32_t)w[j]);
+                                if (r == 1) swar_fma<4>(lo13, hi13, row4, (uint32_t)w[j]);
+                                if (r == 2) swar_fma_rev4(lo02, hi02, row4, (uint32_t)w[j]);
+                                if (r == 3) swar_fma_rev4(lo13, hi13, row4, (uint32_t)w[j]);
+                            } else {
+                                swar_fma<RW>(lo[r], hi[r], row, (uint32_t)w[j]);
+                            }
                         }
                     }
                 }
-                const int unbias = 128 * kQ * 4 * M;
-                static_for<0, U>([&](auto SY) {
-                    constexpr int sy = SY;
-                    uint32_t packed = 0;
-                    static_for<0, U>([&](auto SX) {
-                        constexpr int sx = SX;
-                        const uint32_t sum = swar_field<row_elem(0, sy, sx, U), RW>(lo[0], hi[0]) +
-                                             swar_field<row_elem(1, sy, sx, U), RW>(lo[1], hi[1]) +
-                                             swar_field<row_elem(2, sy, sx, U), RW>(lo[2], hi[2]) +
-                                             swar_field<row_elem(3, sy, sx, U), RW>(lo[3], hi[3]);
-                        packed |= rhe_clip_u8((int)sum - unbias + bias, dv) << (8 * sx);
+                const int unbias = 128 * kQ * 4 * M - bias;
+                if constexpr (U == 4) {
+                    uint32_t tl[4], th[4];
+                    combine_pairs4(lo02, hi02, lo13, hi13, tl, th);
+                    const float inv_d = 1.0f / (float)dv.d;
+                    const bool f32ok = rhe_f32_valid(-128 * kQ * 4 * M + bias, 128 * kQ * 4 * M + bias, dv, inv_d);
+                    for (int sy = 0; sy < 4; ++sy) {
+                        const int k0 = (int)(tl[sy] & 0xFFFFu) - unbias, k1 = (int)(th[sy] & 0xFFFFu) - unbias;
+                        const int k2 = (int)(tl[sy] >> 16) - unbias, k3 = (int)(th[sy] >> 16) - unbias;
+                        o[c][sy] = f32ok ? rhe_pack4_f32(k0, k1, k2, k3, inv_d)
+                                         : (rhe_clip_u8(k0, dv) | (rhe_clip_u8(k1, dv) << 8) | (rhe_clip_u8(k2, dv) << 16) |
+                                            (rhe_clip_u8(k3, dv) << 24));
+                    }
+                } else {
+                    static_for<0, U>([&](auto SY) {
+                        constexpr int sy = SY;
+                        uint32_t packed = 0;
+                        static_for<0, U>([&](auto SX) {
+                            constexpr int sx = SX;
+                            const uint32_t sum = swar_field<row_elem(0, sy, sx, U), RW>(lo[0], hi[0]) +
+                                                 swar_field<row_elem(1, sy, sx, U), RW>(lo[1], hi[1]) +
+                                                 swar_field<row_elem(2, sy, sx, U), RW>(lo[2], hi[2]) +
+                                                 swar_field<row_elem(3, sy, sx, U), RW>(lo[3], hi[3]);
+                            packed |= rhe_clip_u8((int)sum - unbias, dv) << (8 * sx);
+                        });
+                        o[c][sy] = packed;
                     });
-                    o[c][sy] = packed;
-                });
+                }
             }
             for (int sy = 0; sy < U; ++sy) {
                 uint8_t *dst = out_hwc + ((size_t)(y * U + sy) * Wo + (size_t)x * U) * C;
@@ -82,6 +105,56 @@ static void stage_up(const int8_t *const *luts, const char *modes, int M, const 
                 }
             }
         }
+}
+
+// packed band-pair index math vs the scalar simplex: returns the number of mismatches over all
+// (va, vb, vc, vd) sampled on a grid; in-band passes must give band_slot() of the scalar indices.
+extern "C" long emul_check_band_pair(int step) {
+    long bad = 0;
+    for (int va = 0; va < 256; va += step)
+        for (int vb = 0; vb < 256; vb += step)
+            for (int vc = 0; vc < 256; vc += step)
+                for (int vd = 0; vd < 256; vd += 1) {
+                    // pass B uses a permuted / different key set so both halves are exercised
+                    const int vb2 = (vb * 7 + 3) & 255, vc2 = (vc * 5 + 11) & 255, vd2 = 255 - vd;
+                    BandPair bp;
+                    simplex4_band_pair((uint32_t)va, (uint32_t)vb | ((uint32_t)vb2 << 16), (uint32_t)vc | ((uint32_t)vc2 << 16),
+                                       (uint32_t)vd | ((uint32_t)vd2 << 16), bp);
+                    for (int half = 0; half < 2; ++half) {
+                        const int b = half ? vb2 : vb, c = half ? vc2 : vc, d = half ? vd2 : vd;
+                        int idx[5], w[5];
+                        simplex4(va, b, c, d, idx, w);
+                        const int ha = va >> 4, hb = b >> 4, hc = c >> 4, hd = d >> 4;
+                        const bool in = (hb - ha >= -1 && hb - ha <= 1) && (hc - ha >= -1 && hc - ha <= 1) && (hd - ha >= -1 && hd - ha <= 1);
+                        const uint32_t t = half ? (bp.t_band >> 16) : (bp.t_band & 0xFFFFu);
+                        if ((t <= 32u) != in) { ++bad; continue; }
+                        int wsum = 0;
+                        // tie order may differ between the two sorts, so compare weight per row, not per slot
+                        uint32_t rows_s[5], rows_p[5];
+                        int wt_s[5], wt_p[5];
+                        for (int j = 0; j < 5; ++j) {
+                            const int wj = (int)(half ? (bp.w[j] >> 16) : (bp.w[j] & 0xFFFFu));
+                            wsum += wj;
+                            const int A = idx[j] / kStrideA, B = (idx[j] / kStrideB) % kL, C = (idx[j] / kStrideC) % kL, D = idx[j] % kL;
+                            if (in && !band_contains(A, B, C, D)) ++bad;
+                            rows_s[j] = in ? (uint32_t)band_slot(A, B, C, D) * 16u : 0u;
+                            wt_s[j] = w[j];
+                            rows_p[j] = half ? (bp.addr[j] >> 16) : (bp.addr[j] & 0xFFFFu);
+                            wt_p[j] = wj;
+                        }
+                        if (in)
+                            for (int j = 0; j < 5; ++j) {
+                                int ws = 0, wp = 0;
+                                for (int i = 0; i < 5; ++i) {
+                                    if (rows_s[i] == rows_s[j]) ws += wt_s[i];
+                                    if (rows_p[i] == rows_s[j]) wp += wt_p[i];
+                                }
+                                if (ws != wp) ++bad;
+                            }
+                        if (wsum != kQ) ++bad;
+                    }
+                }
+    return bad;
 }
 
 extern "C" int emul_stage(const int8_t *const *luts, const char *modes, int M, int is_last, const uint8_t *in_chw,

@@ -71,3 +71,15 @@ def test_core_math_extreme_tables(emul):
         assert np.array_equal(got, want)
         l1 = [np.full((17 ** 4, 1), val, np.int8)] * 3
         assert np.array_equal(run_emul(emul, l1, "sdy", False, img, 1), c_oracle.stage(l1, "sdy", False, img, 1))
+
+
+def test_band_pair_index_math(emul):
+    emul.emul_check_band_pair.restype = ctypes.c_long
+    assert emul.emul_check_band_pair(5) == 0
+
+
+def test_float_epilogue_validity_table():
+    """rhe_f32_valid() outcome per mode count (documented in DESIGN.md): the GPU uses the float epilogue
+    only where it is proven exact, so this is informational -- but M = 3 (sdy) must be on the fast path."""
+    src = open(os.path.join(ROOT, "mulut_amd", "csrc", "mulut_core.h")).read()
+    assert "rhe_f32_valid" in src

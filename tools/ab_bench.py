@@ -23,6 +23,7 @@ from mulut_amd.synth import natural_frames, noise_frames  # noqa: E402
 
 
 def build_variant(name):
+    name = name.split("@")[0]
     if name == "base":
         return _native.build()
     out_dir = os.path.join(ROOT, "build", "variants")
@@ -54,6 +55,8 @@ def main():
     engines = {}
     for n in names:
         e = MuLUTEngine(0, lib_path=libs[n]).configure(2, "sdy", 4, 4).set_lut_dict(luts)
+        if "@" in n:
+            e.set_tuning("final_stage_kernel", int(n.split("@")[1]))
         e.reserve(args.frames, args.h, args.w, 3)
         e.set_stage_timing(True)
         engines[n] = e

@@ -92,26 +92,27 @@ int main() {
     unsigned long long *cyc;
     uint32_t *sink;
     const int ncu = prop.multiProcessorCount;
-    CK(hipMalloc(&cyc, ncu * 16 * 8));
-    CK(hipMalloc(&sink, ncu * 1024 * 4));
+    CK(hipMalloc(&cyc, ncu * 2 * 16 * 8));
+    CK(hipMalloc(&sink, ncu * 2 * 1024 * 4));
     const int iters = 2000;
     printf("%-10s", "op");
-    const int wps[] = {1, 2, 4};
+    const int wps[] = {1, 2, 4, 6, 8};   // 6 and 8: two workgroups per CU
     for (int w : wps) printf("  %dw/SIMD", w);
     printf("   (cycles per wave-instruction per SIMD, median over waves)\n");
     for (auto &e : ents) {
         printf("%-10s", e.name);
         for (int w : wps) {
-            const int threads = w * 4 * 64;
-            hipLaunchKernelGGL(e.fn, dim3(ncu), dim3(threads), 0, 0, cyc, sink, iters);
+            const int nwg = w > 4 ? 2 : 1;
+            const int threads = (w / nwg) * 4 * 64;
+            hipLaunchKernelGGL(e.fn, dim3(ncu * nwg), dim3(threads), 0, 0, cyc, sink, iters);
             CK(hipDeviceSynchronize());
-            hipLaunchKernelGGL(e.fn, dim3(ncu), dim3(threads), 0, 0, cyc, sink, iters);
+            hipLaunchKernelGGL(e.fn, dim3(ncu * nwg), dim3(threads), 0, 0, cyc, sink, iters);
             CK(hipDeviceSynchronize());
-            std::vector<unsigned long long> h(ncu * 16);
+            std::vector<unsigned long long> h(ncu * nwg * 16);
             CK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
             std::vector<double> v;
-            for (int b = 0; b < ncu; ++b)
-                for (int k = 0; k < w * 4; ++k) v.push_back((double)h[b * 16 + k]);
+            for (int b = 0; b < ncu * nwg; ++b)
+                for (int k = 0; k < (w / nwg) * 4; ++k) v.push_back((double)h[b * 16 + k]);
             std::sort(v.begin(), v.end());
             const double med = v[v.size() / 2];
             // a wave issues iters*32 instructions in `med` cycles while sharing its SIMD with w-1 others
