@@ -118,7 +118,7 @@ int mulut_set_stage_timing(mulut_ctx *ctx, int enable);
 int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap);
 
 /* Tuning knobs (never change results).  "final_stage_kernel": 0 = auto, 1 = full-table gather
- * kernel, 2 = LDS-band kernel (scale 4, <= 3 modes).  Unknown key or value: MULUT_EINVAL. */
+ * kernel, 2 = compact LDS-band kernel, 3 = expanded LDS-band kernel (2, 3: scale 4, <= 3 modes).  Unknown key or value: MULUT_EINVAL. */
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value);
 
 /* Name of the kernel variant used for the final / non-final stage (for profiles). */

@@ -17,6 +17,7 @@ using namespace mulut;
 struct DevTable {
     void *dev = nullptr;    // full table image
     void *band = nullptr;   // diagonal band image (v_num == 16 only), kBandRows x 16 B
+    void *bandx = nullptr;  // the same rows expanded to 16-bit fields, kBandRows x 32 B
     int vnum = 0;
     size_t bytes = 0;
 };
@@ -33,7 +34,7 @@ struct mulut_ctx {
     size_t ws_bytes = 0;
     std::string hip_err;
     int num_cus = 256;
-    int final_kernel = 0;   // 0 auto, 1 full-table gather kernel, 2 LDS band kernel
+    int final_kernel = 0;   // 0 auto (= 3), 1 full-table gather kernel, 2 compact LDS band, 3 expanded LDS band
     int f32_ok[2] = {0, 0}; // float epilogue proven exact for the [non-final, final] divisor
     bool timing = false;
     hipEvent_t ev[MULUT_MAX_STAGES + 1] = {};
@@ -101,6 +102,7 @@ int mulut_destroy(mulut_ctx *ctx) {
         {
             if (t.dev) (void)hipFree(t.dev);
             if (t.band) (void)hipFree(t.band);
+            if (t.bandx) (void)hipFree(t.bandx);
         }
     for (auto &w : ctx->ws)
         if (w) (void)hipFree(w);
@@ -182,9 +184,21 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
                     }
         if (!t.band) HIP_TRY(ctx, hipMalloc(&t.band, band.size()));
         HIP_TRY(ctx, hipMemcpy(t.band, band.data(), band.size(), hipMemcpyHostToDevice));
+        // expanded: LO plane (lo_k = e(4k) | e(4k+2) << 16) then HI plane (hi_k = e(4k+1) | e(4k+3) << 16),
+        // 16-byte rows at the compact band's offsets, each plane padded to whole 1-KiB LDS-DMA pieces
+        std::vector<uint32_t> bx((size_t)2 * kBandXPlaneBytes / 4, 0u);
+        for (int r = 0; r < kBandRows; ++r)
+            for (int k = 0; k < 4; ++k) {
+                const uint8_t *e = &band[(size_t)r * 16 + 4 * k];
+                bx[(size_t)r * 4 + k] = (uint32_t)e[0] | ((uint32_t)e[2] << 16);
+                bx[(size_t)kBandXPlaneBytes / 4 + (size_t)r * 4 + k] = (uint32_t)e[1] | ((uint32_t)e[3] << 16);
+            }
+        if (!t.bandx) HIP_TRY(ctx, hipMalloc(&t.bandx, bx.size() * 4));
+        HIP_TRY(ctx, hipMemcpy(t.bandx, bx.data(), bx.size() * 4, hipMemcpyHostToDevice));
     } else if (t.band) {
         HIP_TRY(ctx, hipFree(t.band));
-        t.band = nullptr;
+        HIP_TRY(ctx, hipFree(t.bandx));
+        t.band = t.bandx = nullptr;
     }
     return MULUT_OK;
 }
@@ -277,9 +291,14 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || C == 1)) mode = kOutPlanarU4;
         else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3) mode = kOutPackedRGBU4;
         if (band) {
+            const bool x = ctx->final_kernel != 2;   // auto / 3: expanded band; 2: compact band
             BandArgs b;
-            for (int m = 0; m < ctx->n_modes; ++m) b.band[m] = ctx->tab[stage - 1][pattern_id(ctx->modes[m])].band;
-            HIP_TRY(ctx, launch_stage_band(a, b, mode, ctx->num_cus, st));
+            for (int m = 0; m < ctx->n_modes; ++m) {
+                const DevTable &t = ctx->tab[stage - 1][pattern_id(ctx->modes[m])];
+                b.band[m] = x ? t.bandx : t.band;
+            }
+            if (x) HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
+            else HIP_TRY(ctx, launch_stage_band(a, b, mode, ctx->num_cus, st));
         } else {
             HIP_TRY(ctx, launch_stage_up(a, u, mode, st));
         }
@@ -395,7 +414,7 @@ int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap) {
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return MULUT_EINVAL;
     if (!strcmp(key, "final_stage_kernel")) {
-        if (value < 0 || value > 2) return MULUT_EINVAL;
+        if (value < 0 || value > 3) return MULUT_EINVAL;
         ctx->final_kernel = value;
         return MULUT_OK;
     }
@@ -405,7 +424,8 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
 const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (!ctx || !ctx->configured) return "";
     if (!is_final || ctx->scale == 1) return stage_u1_name();
-    if (ctx->scale == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1) return stage_band_name(kOutPackedRGBU4);
+    if (ctx->scale == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1)
+        return ctx->final_kernel == 2 ? stage_band_name(kOutPackedRGBU4) : stage_bandx_name(kOutPackedRGBU4);
     return stage_up_name(ctx->scale, ctx->scale == 4 ? kOutPackedRGBU4 : kOutGeneric);
 }
 

@@ -334,6 +334,35 @@ MULUT_HD void swar_fma_rev4_pk(uint32_t (&lo)[4], uint32_t (&hi)[4], const uint3
     }
 }
 
+// ---- expanded band rows (32 B): [lo0 lo1 lo2 lo3 | hi0 hi1 hi2 hi3], lo_k = e(4k) | e(4k+2) << 16,
+// hi_k = e(4k+1) | e(4k+3) << 16 -- the SWAR fields ready-made, so a row costs 8 v_pk_mad_u16 and
+// no unpack.  The reversed (rotation r+2) form swaps the halves of src0 with op_sel for free.
+template <int HALF>
+MULUT_HD uint32_t pk_mad_w_swap(uint32_t x, uint32_t wpk, uint32_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const mulut_u16x2 wv = MULUT_PK(wpk);
+    const mulut_u16x2 ws = __builtin_shufflevector(wv, wv, HALF, HALF);
+    const mulut_u16x2 xv = MULUT_PK(x);
+    return MULUT_UNPK(__builtin_shufflevector(xv, xv, 1, 0) * ws + MULUT_PK(acc));
+#else
+    return pk_mad_w<HALF>((x >> 16) | (x << 16), wpk, acc);
+#endif
+}
+template <int HALF>
+MULUT_HD void swar_fma_x4(uint32_t (&lo)[4], uint32_t (&hi)[4], const uint32_t (&rlo)[4], const uint32_t (&rhi)[4], uint32_t wpk) {
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = pk_mad_w<HALF>(rlo[k], wpk, lo[k]);
+        hi[k] = pk_mad_w<HALF>(rhi[k], wpk, hi[k]);
+    }
+}
+template <int HALF>
+MULUT_HD void swar_fma_x4_rev(uint32_t (&lo)[4], uint32_t (&hi)[4], const uint32_t (&rlo)[4], const uint32_t (&rhi)[4], uint32_t wpk) {
+    for (int k = 0; k < 4; ++k) {
+        lo[3 - k] = pk_mad_w_swap<HALF>(rhi[k], wpk, lo[3 - k]);
+        hi[3 - k] = pk_mad_w_swap<HALF>(rlo[k], wpk, hi[3 - k]);
+    }
+}
+
 // Sum of both pair accumulators in output order (u = 4): S[e0] = acc02[e0] + acc13[e1] with
 // e0 = 4*sy+sx (rotation-0 layout == block layout) and e1 = (3-sx)*4 + sy (rotation-1 layout).
 MULUT_HD void combine_pairs4(const uint32_t (&lo02)[4], const uint32_t (&hi02)[4], const uint32_t (&lo13)[4],

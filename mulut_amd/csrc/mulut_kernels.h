@@ -50,6 +50,9 @@ struct PassArgs {
     signed char di[3], dj[3];
 };
 
+// expanded band image: LO plane then HI plane, each kBandXPlaneBytes (16-byte rows, padded to 1 KiB)
+constexpr int kBandXPlaneBytes = ((kBandRows * 16 + 1023) / 1024) * 1024;
+
 struct BandArgs {
     const void *band[3];   // device images of the diagonal band of each mode's table (kBandRows x 16 B)
 };
@@ -63,6 +66,9 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st);
 hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t st);
 // final stage, u == 4, M <= 3: band tables resident in LDS, persistent workgroups
 hipError_t launch_stage_band(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
+// same, with the band rows expanded to 16-bit fields in LDS (one mode resident, mode loop outermost)
+hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
+const char *stage_bandx_name(int out_mode);
 void stage_band_tile(int &tw, int &th);
 const char *stage_band_name(int out_mode);
 void stage_u1_tile(int &tw, int &th);

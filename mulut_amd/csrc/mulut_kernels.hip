@@ -18,6 +18,7 @@
 // build/ablate/; the shipped library is always built with MULUT_ABLATE == 0.
 //   K2:  1 every row gather reads row 0   2 no gathers (rows synthesised)   3 gathers, no SWAR fma
 //   K2:  4 SWAR fma without the byte unpack    5 epilogue without divide/round/clip
+//   band K2 fast path:  6 xor instead of MAC   7 no LDS row gathers   8 no pixel reads / hoistable index math
 //   K1: 11 every LUT read hits byte 0     12 no LUT reads                   13 no table staging
 #ifndef MULUT_ABLATE
 #define MULUT_ABLATE 0
@@ -117,6 +118,14 @@ __device__ __forceinline__ void decode_tile(const StageArgs &a, int tile, int &n
     x0 = tx * TW;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share one L2), so give each XCD
+// a contiguous range of tiles: neighbouring tiles then share the 128-B lines their halos straddle in
+// ONE L2 instead of fetching them from HBM twice.  Bijective for any n (cdna guide T1).
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, xcd = id & 7, idx = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: stage with 1-byte rows.  One workgroup = one TH x TW pixel tile x all channels.
 // LDS: [ table of the active mode : 83536 B ][ image tile C*(TH+4)*(TW+4) B ]
@@ -129,7 +138,7 @@ __global__ void __launch_bounds__(NT) stage_u1_kernel(StageArgs a) {
     uint8_t *s_img = smem + kU1TableBytes;
 
     int n, y0, x0;
-    decode_tile(a, blockIdx.x, n, y0, x0, TW, TH);
+    decode_tile(a, xcd_remap(blockIdx.x, gridDim.x), n, y0, x0, TW, TH);
     load_tile<TW, TH, NT>(a, n, y0, x0, s_img);
 
     const int nsamp = a.C * TH * TW;
@@ -301,6 +310,14 @@ struct RotAcc<4> {
         if constexpr (R == 2) swar_fma_rev4_pk<HALF>(lo02, hi02, row, wpk);
         if constexpr (R == 3) swar_fma_rev4_pk<HALF>(lo13, hi13, row, wpk);
     }
+    // expanded 32-B band rows (ready-made SWAR fields)
+    template <int R, int HALF>
+    __device__ __forceinline__ void fma_x(const uint32_t (&rlo)[4], const uint32_t (&rhi)[4], uint32_t wpk) {
+        if constexpr (R == 0) swar_fma_x4<HALF>(lo02, hi02, rlo, rhi, wpk);
+        if constexpr (R == 1) swar_fma_x4<HALF>(lo13, hi13, rlo, rhi, wpk);
+        if constexpr (R == 2) swar_fma_x4_rev<HALF>(lo02, hi02, rlo, rhi, wpk);
+        if constexpr (R == 3) swar_fma_x4_rev<HALF>(lo13, hi13, rlo, rhi, wpk);
+    }
     // after finalize(): lo02/hi02 hold the sum of all four rotations in block order
     __device__ __forceinline__ void finalize() {
         uint32_t lo[4], hi[4];
@@ -418,7 +435,7 @@ __global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
     uint8_t *s_img = smem;
 
     int n, y0, x0;
-    decode_tile(a, blockIdx.x, n, y0, x0, TW, TH);
+    decode_tile(a, xcd_remap(blockIdx.x, gridDim.x), n, y0, x0, TW, TH);
     load_tile<TW, TH, NT>(a, n, y0, x0, s_img);
     __syncthreads();
 
@@ -522,7 +539,11 @@ __global__ void __launch_bounds__(TW *TH) stage_band_kernel(StageArgs a, BandArg
     constexpr int U = 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_band = smem;
-    uint8_t *s_img = smem + a.M * kBandBytes;
+    // per-thread staging of the finished channels' packed rows (RGB path): [c][tid] x 16 B.  Keeping
+    // them in "registers" across the runtime channel loop made the compiler spill them to scratch,
+    // which doubled the kernel's HBM write traffic (profiles/r01_v2_pmc_*).
+    uint4 *s_out = (uint4 *)(smem + a.M * kBandBytes);
+    uint8_t *s_img = smem + a.M * kBandBytes + (OUT == kOutPackedRGBU4 ? 3 * NT * 16 : 0);
 
     for (int m = 0; m < a.M; ++m) {
         const uint4 *src = (const uint4 *)b.band[m];
@@ -531,7 +552,14 @@ __global__ void __launch_bounds__(TW *TH) stage_band_kernel(StageArgs a, BandArg
     }
     const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
     const int ntiles = a.N * a.tiles_x * a.tiles_y;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // persistent workgroups; XCD x (= blockIdx % 8) walks its own contiguous eighth of the tiles
+    const int G = gridDim.x;
+    const bool by_xcd = (G & 7) == 0;
+    const int per = (ntiles + 7) >> 3;
+    const int first = by_xcd ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int last = by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, ntiles) : ntiles;
+    const int step = by_xcd ? (G >> 3) : G;
+    for (int tile = first; tile < last; tile += step) {
         int n, y0, x0;
         decode_tile(a, tile, n, y0, x0, TW, TH);
         __syncthreads();  // band staged (first trip) / everyone done reading the previous tile
@@ -540,7 +568,6 @@ __global__ void __launch_bounds__(TW *TH) stage_band_kernel(StageArgs a, BandArg
         const int y = y0 + ty, x = x0 + tx;
         if (y >= a.oy1 || x >= a.W) continue;   // no barrier below this point inside the trip
 
-        uint32_t oR[U], oG[U], oB[U];
         for (int c = 0; c < a.C; ++c) {
             const uint8_t *ctr = s_img + c * (PH * PW) + (ty + kHalo) * PW + (tx + kHalo);
             const int va = ctr[0];
@@ -558,19 +585,62 @@ __global__ void __launch_bounds__(TW *TH) stage_band_kernel(StageArgs a, BandArg
                     sample_offset(r, di0, dj0, dy, dx); const int o0 = dy * PW + dx;
                     sample_offset(r, di1, dj1, dy, dx); const int o1 = dy * PW + dx;
                     sample_offset(r, di2, dj2, dy, dx); const int o2 = dy * PW + dx;
+#if MULUT_ABLATE == 8   /* timing-only: no pixel reads, index math hoistable out of the mode loop */
+                    const int b0 = va, b1 = va, c0 = va, c1 = va, d0 = va, d1 = va;
+#else
                     const int b0 = ctr[o0], b1 = ctr[-o0], c0 = ctr[o1], c1 = ctr[-o1], d0 = ctr[o2], d1 = ctr[-o2];
+#endif
                     BandPair bp;
                     simplex4_band_pair((uint32_t)va, (uint32_t)b0 | ((uint32_t)b1 << 16), (uint32_t)c0 | ((uint32_t)c1 << 16),
                                        (uint32_t)d0 | ((uint32_t)d1 << 16), bp);
-                    pass_band<r, 0>(band, lut, bp, va, b0, c0, d0, a, acc);
-                    pass_band<r + 2, 1>(band, lut, bp, va, b1, c1, d1, a, acc);
+                    // both halves <= 32 in every lane (wave-uniform): straight-line band path, the ten row
+                    // reads of the two passes issue together and overlap the first pass's MACs
+                    const bool in_both = ((bp.t_band & 0xFFFFu) <= 32u) & ((bp.t_band >> 16) <= 32u);
+                    if (__all(in_both)) {
+                        uint32_t rowA[5][4], rowB[5][4];
+#if MULUT_ABLATE == 7   /* timing-only: no LDS row gathers */
+#pragma unroll
+                        for (int j = 0; j < 5; ++j)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { rowA[j][k] = bp.addr[j] + k; rowB[j][k] = bp.addr[j] ^ k; }
+#else
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            const uint4 v = *(const uint4 *)(band + (bp.addr[j] & 0xFFFFu));
+                            rowA[j][0] = v.x; rowA[j][1] = v.y; rowA[j][2] = v.z; rowA[j][3] = v.w;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            const uint4 v = *(const uint4 *)(band + (bp.addr[j] >> 16));
+                            rowB[j][0] = v.x; rowB[j][1] = v.y; rowB[j][2] = v.z; rowB[j][3] = v.w;
+                        }
+#endif
+#if MULUT_ABLATE == 6   /* timing-only: rows folded with one xor each instead of the SWAR MAC */
+#pragma unroll
+                        for (int j = 0; j < 5; ++j)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { acc.lo02[k] ^= rowA[j][k] + bp.w[j]; acc.lo13[k] ^= rowB[j][k] + bp.w[j]; }
+#else
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) acc.template fma_pk<r, 0>(rowA[j], bp.w[j]);
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) acc.template fma_pk<r + 2, 1>(rowB[j], bp.w[j]);
+#endif
+                    } else {
+                        pass_band<r, 0>(band, lut, bp, va, b0, c0, d0, a, acc);
+                        pass_band<r + 2, 1>(band, lut, bp, va, b1, c1, d1, a, acc);
+                    }
                 });
             }
             uint32_t o[U];
             finish_channel<U, OUT>(a, acc, n, c, y, x, o);
-            if constexpr (OUT == kOutPackedRGBU4) keep_rgb<U>(c, o, oR, oG, oB);
+            if constexpr (OUT == kOutPackedRGBU4) s_out[c * NT + threadIdx.x] = make_uint4(o[0], o[1], o[2], o[3]);
         }
-        if constexpr (OUT == kOutPackedRGBU4) store_rgb<U>(a, n, y, x, oR, oG, oB);
+        if constexpr (OUT == kOutPackedRGBU4) {
+            const uint4 R = s_out[threadIdx.x], Gc = s_out[NT + threadIdx.x], B = s_out[2 * NT + threadIdx.x];
+            const uint32_t oR[4] = {R.x, R.y, R.z, R.w}, oG[4] = {Gc.x, Gc.y, Gc.z, Gc.w}, oB[4] = {B.x, B.y, B.z, B.w};
+            store_rgb<U>(a, n, y, x, oR, oG, oB);
+        }
     }
 }
 
@@ -584,12 +654,13 @@ const char *stage_band_name(int out_mode) {
 template <int OUT>
 static hipError_t launch_band_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
     auto kern = stage_band_kernel<OUT, KB_TW, KB_TH>;
-    const size_t lds = (size_t)a.M * kBandBytes + (size_t)a.C * (KB_TH + 2 * kHalo) * (KB_TW + 2 * kHalo);
+    const size_t lds = (size_t)a.M * kBandBytes + (OUT == kOutPackedRGBU4 ? 3 * KB_TW * KB_TH * 16 : 0) +
+                       (size_t)a.C * (KB_TH + 2 * kHalo) * (KB_TW + 2 * kHalo);
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
@@ -605,6 +676,175 @@ hipError_t launch_stage_band(const StageArgs &a, const BandArgs &b, int out_mode
     if (out_mode == kOutPlanarU4) return launch_band_t<kOutPlanarU4>(a, b, num_cus, st);
     if (out_mode == kOutPackedRGBU4 && a.C == 3) return launch_band_t<kOutPackedRGBU4>(a, b, num_cus, st);
     return launch_band_t<kOutGeneric>(a, b, num_cus, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2-band-x: as stage_band_kernel, but the band rows live in LDS EXPANDED to 16-bit fields, so the
+// MAC is 8 v_pk_mad_u16 per row with no unpack.  A band is two planes of 16-byte rows -- LO
+// (elements 4k | 4k+2 << 16) and HI (4k+1 | 4k+3 << 16) -- so both reads of a row use the compact
+// band offset (the second with an immediate) and bank behaviour equals the compact band's.
+// 68 KB per mode: only the active mode is resident, the mode loop is outermost inside a tile and
+// the accumulators of all channels of a pixel (3 x 16 VGPRs) stay in registers across it.  The next
+// mode's band is brought in by LDS-DMA (global_load_lds_dwordx4) into the other buffer while the
+// current one is being used.
+// LDS: [ band buffer 0 : 69632 B ][ band buffer 1 : 69632 B ][ image tile 0 ][ image tile 1 ]
+// ------------------------------------------------------------------------------------------
+constexpr int kPlaneBytes = ((kBandRows * 16 + 1023) / 1024) * 1024;   // 34816: one LDS-DMA piece is 1 KiB
+constexpr int kBandXBytes = 2 * kPlaneBytes;                          // 69632
+
+// asynchronous global -> LDS copy of one expanded band; every wave moves whole 1-KiB pieces
+template <int NT>
+__device__ __forceinline__ void band_dma(const uint8_t *gsrc, uint8_t *lds_dst) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int piece = wave; piece < kBandXBytes / 1024; piece += NT / 64) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + piece * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void *)(lds_dst + piece * 1024), 16, 0, 0);
+    }
+}
+
+template <int R, int HALF>
+__device__ __forceinline__ void rows_x(const uint8_t *band, const BandPair &bp, RotAcc<4> &acc) {
+    // depth-1 software pipeline over the five rows: row j+1 is in flight while row j is accumulated
+    // (all five at once would need 40 VGPRs next to the 48 accumulators of the three channels)
+    uint4 c0, c1, n0, n1;
+    auto ld = [&](int j, uint4 &v0, uint4 &v1) {
+        const uint32_t off = HALF ? (bp.addr[j] >> 16) : (bp.addr[j] & 0xFFFFu);
+        v0 = *(const uint4 *)(band + off);
+        v1 = *(const uint4 *)(band + off + kPlaneBytes);
+    };
+    ld(0, c0, c1);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        if (j < 4) ld(j + 1, n0, n1);
+        const uint32_t rlo[4] = {c0.x, c0.y, c0.z, c0.w}, rhi[4] = {c1.x, c1.y, c1.z, c1.w};
+        acc.template fma_x<R, HALF>(rlo, rhi, bp.w[j]);
+        c0 = n0;
+        c1 = n1;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void pair_x(const uint8_t *band, const void *lut, const uint8_t *ctr, int o0, int o1, int o2,
+                                       const StageArgs &a, RotAcc<4> &acc) {
+    const int va = ctr[0];
+    const int b0 = ctr[o0], b1 = ctr[-o0], c0 = ctr[o1], c1 = ctr[-o1], d0 = ctr[o2], d1 = ctr[-o2];
+    BandPair bp;
+    simplex4_band_pair((uint32_t)va, (uint32_t)b0 | ((uint32_t)b1 << 16), (uint32_t)c0 | ((uint32_t)c1 << 16),
+                       (uint32_t)d0 | ((uint32_t)d1 << 16), bp);
+    const bool inA = (bp.t_band & 0xFFFFu) <= 32u, inB = (bp.t_band >> 16) <= 32u;
+    if (__all(inA & inB)) {
+        rows_x<R, 0>(band, bp, acc);
+        rows_x<R + 2, 1>(band, bp, acc);
+    } else {
+        if (inA) rows_x<R, 0>(band, bp, acc); else pass_global<4, R>(lut, va, b0, c0, d0, a, acc);
+        if (inB) rows_x<R + 2, 1>(band, bp, acc); else pass_global<4, R + 2>(lut, va, b1, c1, d1, a, acc);
+    }
+}
+
+template <int OUT, int TW, int TH>
+__global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandArgs b) {
+    constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
+    constexpr int NT = TW * TH;
+    constexpr int U = 4;
+    constexpr int kTileBytes = ((3 * PH * PW + 15) / 16) * 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *s_band = smem;                       // two buffers of kBandXBytes
+    uint8_t *s_tile = smem + 2 * kBandXBytes;     // two buffers of kTileBytes
+
+    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    const int G = gridDim.x;
+    const bool by_xcd = (G & 7) == 0;
+    const int per = (ntiles + 7) >> 3;
+    const int first = by_xcd ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int last = by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, ntiles) : ntiles;
+    const int step = by_xcd ? (G >> 3) : G;
+
+    int phase = 0;   // counts (tile, mode) steps of this workgroup: band buffer = phase & 1
+    if (first < last) band_dma<NT>((const uint8_t *)b.band[0], s_band);
+    for (int tile = first, it = 0; tile < last; tile += step, ++it) {
+        int n, y0, x0;
+        decode_tile(a, tile, n, y0, x0, TW, TH);
+        uint8_t *s_img = s_tile + (it & 1) * kTileBytes;
+        load_tile<TW, TH, NT>(a, n, y0, x0, s_img);   // the buffer last read two tiles ago
+        const int y = y0 + ty, x = x0 + tx;
+        const bool valid = y < a.oy1 && x < a.W;
+        const uint8_t *ctr = s_img + (ty + kHalo) * PW + (tx + kHalo);
+        RotAcc<4> acc0, acc1, acc2;
+        acc0.clear(); acc1.clear(); acc2.clear();
+        for (int mv = 0; mv < a.M; ++mv, ++phase) {
+            const int m = __builtin_amdgcn_readfirstlane(mv);
+            // my DMA pieces of this phase's band have landed; after the barrier everyone's have, the image
+            // tile is visible, and every wave has finished the previous phase (its band buffer is free)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const uint8_t *band = s_band + (phase & 1) * kBandXBytes;
+            {   // prefetch the next phase's band (next mode, or mode 0 of the next tile) into the other buffer
+                const int mnext = mv + 1 < a.M ? mv + 1 : 0;
+                if (mv + 1 < a.M || tile + step < last)
+                    band_dma<NT>((const uint8_t *)b.band[__builtin_amdgcn_readfirstlane(mnext)],
+                                 s_band + ((phase + 1) & 1) * kBandXBytes);
+            }
+            if (valid) {
+                const void *lut = a.lut[m];
+                int dy, dx;
+                sample_offset(0, a.di[m][0], a.dj[m][0], dy, dx); const int p0 = dy * PW + dx;
+                sample_offset(0, a.di[m][1], a.dj[m][1], dy, dx); const int p1 = dy * PW + dx;
+                sample_offset(0, a.di[m][2], a.dj[m][2], dy, dx); const int p2 = dy * PW + dx;
+                sample_offset(1, a.di[m][0], a.dj[m][0], dy, dx); const int q0 = dy * PW + dx;
+                sample_offset(1, a.di[m][1], a.dj[m][1], dy, dx); const int q1 = dy * PW + dx;
+                sample_offset(1, a.di[m][2], a.dj[m][2], dy, dx); const int q2 = dy * PW + dx;
+                pair_x<0>(band, lut, ctr, p0, p1, p2, a, acc0);
+                pair_x<1>(band, lut, ctr, q0, q1, q2, a, acc0);
+                if (a.C > 1) {
+                    pair_x<0>(band, lut, ctr + PH * PW, p0, p1, p2, a, acc1);
+                    pair_x<1>(band, lut, ctr + PH * PW, q0, q1, q2, a, acc1);
+                }
+                if (a.C > 2) {
+                    pair_x<0>(band, lut, ctr + 2 * PH * PW, p0, p1, p2, a, acc2);
+                    pair_x<1>(band, lut, ctr + 2 * PH * PW, q0, q1, q2, a, acc2);
+                }
+            }
+        }
+        if (valid) {
+            uint32_t oR[U], oG[U], oB[U];
+            finish_channel<U, OUT>(a, acc0, n, 0, y, x, oR);
+            if (a.C > 1) finish_channel<U, OUT>(a, acc1, n, 1, y, x, oG);
+            if (a.C > 2) finish_channel<U, OUT>(a, acc2, n, 2, y, x, oB);
+            if constexpr (OUT == kOutPackedRGBU4) store_rgb<U>(a, n, y, x, oR, oG, oB);
+        }
+    }
+}
+
+const char *stage_bandx_name(int out_mode) {
+    return out_mode == kOutPackedRGBU4 ? "stage_bandx_kernel<rgb>" : out_mode == kOutPlanarU4 ? "stage_bandx_kernel<planar>"
+                                                                                               : "stage_bandx_kernel<generic>";
+}
+
+template <int OUT>
+static hipError_t launch_bandx_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
+    auto kern = stage_bandx_kernel<OUT, KB_TW, KB_TH>;
+    const size_t lds = 2 * (size_t)kBandXBytes + 2 * (size_t)(((3 * (KB_TH + 2 * kHalo) * (KB_TW + 2 * kHalo) + 15) / 16) * 16);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
+    if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(ntiles < num_cus ? ntiles : num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(KB_TW * KB_TH), lds, st, a, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st) {
+    if (a.C > 3 || a.M > 3) return hipErrorInvalidValue;
+    if (out_mode == kOutPlanarU4) return launch_bandx_t<kOutPlanarU4>(a, b, num_cus, st);
+    if (out_mode == kOutPackedRGBU4 && a.C == 3) return launch_bandx_t<kOutPackedRGBU4>(a, b, num_cus, st);
+    return launch_bandx_t<kOutGeneric>(a, b, num_cus, st);
 }
 
 }  // namespace mulut

@@ -81,10 +81,35 @@
 #define MK(N) DEFKERNEL(N, A_##N)
 OPS(MK)
 
+// dependent chains: every instruction consumes the previous result (latency, not throughput)
+#define DEFDEP(NAME, ASM3)                                                                            \
+    __global__ void __launch_bounds__(1024) d_##NAME(unsigned long long *cyc, uint32_t *sink, int iters) { \
+        uint32_t a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7;            \
+        uint32_t b = threadIdx.x * 3u + 7u, c = threadIdx.x ^ 0x55u;                                  \
+        __syncthreads();                                                                              \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
+        for (int i = 0; i < iters; ++i) {                                                             \
+            asm volatile(ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") \
+                         ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") \
+                         ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") \
+                         ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") ASM3("%0") \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)     \
+                         : "v"(b), "v"(c));                                                           \
+        }                                                                                             \
+        asm volatile("s_nop 0" ::: "memory");                                                         \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;          \
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;             \
+    }
+#define DEPOPS(X) X(ADD) X(AND) X(MIN) X(MAD24) X(PKMAD) X(PKMIN) X(PERM) X(LSHLOR) X(FMA) X(CVTF)
+#define MKD(N) DEFDEP(N, A_##N)
+DEPOPS(MKD)
+
 typedef void (*kfn)(unsigned long long *, uint32_t *, int);
 struct Ent { const char *name; kfn fn; };
 #define ENT(N) {#N, k_##N},
-static Ent ents[] = {OPS(ENT)};
+#define ENTD(N) {"dep_" #N, d_##N},
+static Ent ents[] = {OPS(ENT) DEPOPS(ENTD)};
 
 int main() {
     hipDeviceProp_t prop;
