@@ -141,12 +141,24 @@ __global__ void __launch_bounds__(NT) stage_u1_kernel(StageArgs a) {
     decode_tile(a, xcd_remap(blockIdx.x, gridDim.x), n, y0, x0, TW, TH);
     load_tile<TW, TH, NT>(a, n, y0, x0, s_img);
 
+    // Sites of this thread: s = tid + k*NT over [C][TH][TW].  With fewer than 3 channels the surplus
+    // sites are folded back onto valid ones (recomputed, never stored), which keeps the loop body free
+    // of per-site branches so that the compiler can interleave the SPT x 4 independent passes.
     const int nsamp = a.C * TH * TW;
+    int ctr_off[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+        int s = threadIdx.x + k * NT;
+        s = s < nsamp ? s : s % (TH * TW);
+        const int tx = s % TW, ty = (s / TW) % TH, c = s / (TW * TH);
+        ctr_off[k] = c * (PH * PW) + (ty + kHalo) * PW + (tx + kHalo);
+    }
     int acc[SPT];
 #pragma unroll
     for (int k = 0; k < SPT; ++k) acc[k] = 0;
 
-    for (int m = 0; m < a.M; ++m) {
+    for (int mv = 0; mv < a.M; ++mv) {
+        const int m = __builtin_amdgcn_readfirstlane(mv);   // SGPR: per-mode arguments by scalar loads
         __syncthreads();  // tile filled (m == 0) / everyone done with the previous table
 #if MULUT_ABLATE != 13
         {
@@ -167,32 +179,43 @@ __global__ void __launch_bounds__(NT) stage_u1_kernel(StageArgs a) {
             }
 #pragma unroll
         for (int k = 0; k < SPT; ++k) {
-            const int s = threadIdx.x + k * NT;
-            if (s < nsamp) {
-                const int tx = s % TW;
-                const int ty = (s / TW) % TH;
-                const int c = s / (TW * TH);
-                const uint8_t *ctr = s_img + c * (PH * PW) + (ty + kHalo) * PW + (tx + kHalo);
-                const int va = ctr[0];
-                int sum = 0;
+            const uint8_t *ctr = s_img + ctr_off[k];
+            const int va = ctr[0];
+            // phases instead of four serial passes: 12 neighbour reads, 4 index computations, 20 table
+            // reads, 20 MACs -- two LDS round trips per site and mode instead of eight
+            int vb[4], vc[4], vd[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int idx[5], w[5];
-                    simplex4(va, ctr[off[r][0]], ctr[off[r][1]], ctr[off[r][2]], idx, w);
+            for (int r = 0; r < 4; ++r) {
+                vb[r] = ctr[off[r][0]];
+                vc[r] = ctr[off[r][1]];
+                vd[r] = ctr[off[r][2]];
+            }
+            int idx[4][5], w[4][5];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) simplex4(va, vb[r], vc[r], vd[r], idx[r], w[r]);
 #if MULUT_ABLATE == 11
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) idx[j] &= (a.N >> 30);
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) idx[r][j] &= (a.N >> 30);
 #endif
+            int lv[4][5];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
 #if MULUT_ABLATE == 12
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) sum += w[j] * idx[j];
+                    lv[r][j] = idx[r][j];
 #else
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) sum += w[j] * (int)s_lut[idx[j]];
+                    lv[r][j] = (int)s_lut[idx[r][j]];
 #endif
                 }
-                acc[k] += sum;
-            }
+            int sum = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) sum += w[r][j] * lv[r][j];
+            acc[k] += sum;
         }
     }
 #pragma unroll
@@ -369,6 +392,35 @@ __device__ __forceinline__ void finish_channel(const StageArgs &a, RotAcc<U> &ac
         if constexpr (OUT == kOutPlanarU4) {
             *(uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n, c, y * U + sy, x * U)) = packed;
         }
+    });
+}
+
+// one packed output row (4 bytes) of a finalized u == 4 accumulator
+template <int SY>
+__device__ __forceinline__ uint32_t finish_row4(const StageArgs &a, const RotAcc<4> &acc) {
+    const int unbias = 128 * kQ * 4 * a.M - a.bias_num;
+    const int k0 = (int)acc.template sum<SY, 0>() - unbias, k1 = (int)acc.template sum<SY, 1>() - unbias;
+    const int k2 = (int)acc.template sum<SY, 2>() - unbias, k3 = (int)acc.template sum<SY, 3>() - unbias;
+    if (a.use_f32) return rhe_pack4_f32(k0, k1, k2, k3, a.inv_d);   // wave-uniform
+    return rhe_clip_u8(k0, a.div) | (rhe_clip_u8(k1, a.div) << 8) | (rhe_clip_u8(k2, a.div) << 16) |
+           (rhe_clip_u8(k3, a.div) << 24);
+}
+
+// RGB epilogue row by row: only three packed rows are live at a time (finishing whole channels first
+// parked 4-12 dwords per pixel in scratch, i.e. extra HBM writes)
+__device__ __forceinline__ void finish_store_rgb4(const StageArgs &a, RotAcc<4> &accR, RotAcc<4> &accG, RotAcc<4> &accB,
+                                                  int n, int y, int x) {
+    accR.finalize();
+    accG.finalize();
+    accB.finalize();
+    static_for<0, 4>([&](auto SY) {
+        constexpr int sy = SY;
+        uint32_t w0, w1, w2;
+        interleave_rgb4(finish_row4<sy>(a, accR), finish_row4<sy>(a, accG), finish_row4<sy>(a, accB), w0, w1, w2);
+        uint32_t *dst = (uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n, 0, y * 4 + sy, x * 4));
+        dst[0] = w0;
+        dst[1] = w1;
+        dst[2] = w2;
     });
 }
 
@@ -712,14 +764,47 @@ __device__ __forceinline__ void rows_x(const uint8_t *band, const BandPair &bp, 
         v0 = *(const uint4 *)(band + off);
         v1 = *(const uint4 *)(band + off + kPlaneBytes);
     };
+#if MULUT_ABLATE == 7   /* timing-only: no LDS row gathers */
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint32_t rlo[4] = {bp.addr[j], bp.addr[j] + 1, bp.addr[j] + 2, bp.addr[j] + 3}, rhi[4] = {bp.addr[j] ^ 1, bp.addr[j] ^ 2, bp.addr[j] ^ 3, bp.addr[j] ^ 4};
+        acc.template fma_x<R, HALF>(rlo, rhi, bp.w[j]);
+    }
+    (void)band; (void)c0; (void)c1; (void)n0; (void)n1; (void)ld;
+#else
     ld(0, c0, c1);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         if (j < 4) ld(j + 1, n0, n1);
         const uint32_t rlo[4] = {c0.x, c0.y, c0.z, c0.w}, rhi[4] = {c1.x, c1.y, c1.z, c1.w};
+#if MULUT_ABLATE == 6   /* timing-only: one xor per dword instead of the MAC */
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc.lo02[k] ^= rlo[k] + bp.w[j]; acc.hi13[k] ^= rhi[k] + bp.w[j]; }
+#else
         acc.template fma_x<R, HALF>(rlo, rhi, bp.w[j]);
+#endif
         c0 = n0;
         c1 = n1;
+    }
+#endif
+}
+
+// rare out-of-band pass inside the expanded-band kernel: one row in flight at a time, so that this path
+// does not set the kernel's register allocation (latency is irrelevant here)
+template <int R>
+__device__ __forceinline__ void pass_global_lean(const void *lut, int va, int vb, int vc, int vd, RotAcc<4> &acc) {
+    int idx[5], w[5];
+    simplex4(va, vb, vc, vd, idx, w);
+#pragma unroll 1
+    for (int j = 0; j < 5; ++j) {
+        int ij = idx[0], wj = w[0];
+        if (j == 1) { ij = idx[1]; wj = w[1]; }
+        if (j == 2) { ij = idx[2]; wj = w[2]; }
+        if (j == 3) { ij = idx[3]; wj = w[3]; }
+        if (j == 4) { ij = idx[4]; wj = w[4]; }
+        uint32_t row[4];
+        load_row<4>(lut, ij, row);
+        acc.template fma<R>(row, (uint32_t)wj);
     }
 }
 
@@ -727,7 +812,12 @@ template <int R>
 __device__ __forceinline__ void pair_x(const uint8_t *band, const void *lut, const uint8_t *ctr, int o0, int o1, int o2,
                                        const StageArgs &a, RotAcc<4> &acc) {
     const int va = ctr[0];
+#if MULUT_ABLATE == 8   /* timing-only: no neighbour reads, index math hoistable */
+    const int b0 = va, b1 = va, c0 = va, c1 = va, d0 = va, d1 = va;
+    (void)o0; (void)o1; (void)o2;
+#else
     const int b0 = ctr[o0], b1 = ctr[-o0], c0 = ctr[o1], c1 = ctr[-o1], d0 = ctr[o2], d1 = ctr[-o2];
+#endif
     BandPair bp;
     simplex4_band_pair((uint32_t)va, (uint32_t)b0 | ((uint32_t)b1 << 16), (uint32_t)c0 | ((uint32_t)c1 << 16),
                        (uint32_t)d0 | ((uint32_t)d1 << 16), bp);
@@ -736,8 +826,8 @@ __device__ __forceinline__ void pair_x(const uint8_t *band, const void *lut, con
         rows_x<R, 0>(band, bp, acc);
         rows_x<R + 2, 1>(band, bp, acc);
     } else {
-        if (inA) rows_x<R, 0>(band, bp, acc); else pass_global<4, R>(lut, va, b0, c0, d0, a, acc);
-        if (inB) rows_x<R + 2, 1>(band, bp, acc); else pass_global<4, R + 2>(lut, va, b1, c1, d1, a, acc);
+        if (inA) rows_x<R, 0>(band, bp, acc); else pass_global_lean<R>(lut, va, b0, c0, d0, acc);
+        if (inB) rows_x<R + 2, 1>(band, bp, acc); else pass_global_lean<R + 2>(lut, va, b1, c1, d1, acc);
     }
 }
 
@@ -781,19 +871,25 @@ __global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandAr
             const uint8_t *band = s_band + (phase & 1) * kBandXBytes;
             {   // prefetch the next phase's band (next mode, or mode 0 of the next tile) into the other buffer
                 const int mnext = mv + 1 < a.M ? mv + 1 : 0;
+#if MULUT_ABLATE != 9   /* 9 = timing-only: bands never restaged */
                 if (mv + 1 < a.M || tile + step < last)
+#else
+                if (false)
+#endif
                     band_dma<NT>((const uint8_t *)b.band[__builtin_amdgcn_readfirstlane(mnext)],
                                  s_band + ((phase + 1) & 1) * kBandXBytes);
             }
             if (valid) {
                 const void *lut = a.lut[m];
+                // wave-uniform LDS offsets of keys b, c, d for rotations 0 and 1 (2 and 3 are their negatives):
+                // pinned to SGPRs, they must not compete with the 48 accumulator VGPRs
                 int dy, dx;
-                sample_offset(0, a.di[m][0], a.dj[m][0], dy, dx); const int p0 = dy * PW + dx;
-                sample_offset(0, a.di[m][1], a.dj[m][1], dy, dx); const int p1 = dy * PW + dx;
-                sample_offset(0, a.di[m][2], a.dj[m][2], dy, dx); const int p2 = dy * PW + dx;
-                sample_offset(1, a.di[m][0], a.dj[m][0], dy, dx); const int q0 = dy * PW + dx;
-                sample_offset(1, a.di[m][1], a.dj[m][1], dy, dx); const int q1 = dy * PW + dx;
-                sample_offset(1, a.di[m][2], a.dj[m][2], dy, dx); const int q2 = dy * PW + dx;
+                sample_offset(0, a.di[m][0], a.dj[m][0], dy, dx); const int p0 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
+                sample_offset(0, a.di[m][1], a.dj[m][1], dy, dx); const int p1 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
+                sample_offset(0, a.di[m][2], a.dj[m][2], dy, dx); const int p2 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
+                sample_offset(1, a.di[m][0], a.dj[m][0], dy, dx); const int q0 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
+                sample_offset(1, a.di[m][1], a.dj[m][1], dy, dx); const int q1 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
+                sample_offset(1, a.di[m][2], a.dj[m][2], dy, dx); const int q2 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
                 pair_x<0>(band, lut, ctr, p0, p1, p2, a, acc0);
                 pair_x<1>(band, lut, ctr, q0, q1, q2, a, acc0);
                 if (a.C > 1) {
@@ -807,11 +903,14 @@ __global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandAr
             }
         }
         if (valid) {
-            uint32_t oR[U], oG[U], oB[U];
-            finish_channel<U, OUT>(a, acc0, n, 0, y, x, oR);
-            if (a.C > 1) finish_channel<U, OUT>(a, acc1, n, 1, y, x, oG);
-            if (a.C > 2) finish_channel<U, OUT>(a, acc2, n, 2, y, x, oB);
-            if constexpr (OUT == kOutPackedRGBU4) store_rgb<U>(a, n, y, x, oR, oG, oB);
+            if constexpr (OUT == kOutPackedRGBU4) {
+                finish_store_rgb4(a, acc0, acc1, acc2, n, y, x);
+            } else {
+                uint32_t o[U];
+                finish_channel<U, OUT>(a, acc0, n, 0, y, x, o);
+                if (a.C > 1) finish_channel<U, OUT>(a, acc1, n, 1, y, x, o);
+                if (a.C > 2) finish_channel<U, OUT>(a, acc2, n, 2, y, x, o);
+            }
         }
     }
 }

@@ -101,15 +101,39 @@ OPS(MK)
         sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;          \
         if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;             \
     }
+// realistic mixes (one of each per 8 instructions, independent registers)
+#define A_MIXA(D) "v_and_b32 " D ", " D ", %8\n v_lshrrev_b32 %1, 4, %1\n v_mad_u32_u24 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n v_pk_mad_u16 %4, %4, %8, %9\n v_min_u32 %5, %5, %8\n v_max_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+#define A_MIXB(D) "v_and_b32 " D ", " D ", %8\n v_lshrrev_b32 %1, 8, %1\n v_and_b32 %2, %2, %9\n v_pk_mad_u16 %3, %3, %8, %9\n v_pk_mad_u16 %4, %4, %8, %9\n v_and_b32 %5, %5, %8\n v_lshrrev_b32 %6, 8, %6\n v_pk_mad_u16 %7, %7, %8, %9\n"
+#define A_MIXC(D) "v_pk_max_u16 " D ", " D ", %8\n v_pk_min_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n v_pk_sub_u16 %3, %3, %8\n v_pk_lshrrev_b16 %4, 12, %4\n v_and_b32 %5, %5, %8\n v_pk_mad_u16 %6, %6, %8, %9\n v_add_u32_sdwa %7, %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
 #define DEPOPS(X) X(ADD) X(AND) X(MIN) X(MAD24) X(PKMAD) X(PKMIN) X(PERM) X(LSHLOR) X(FMA) X(CVTF)
 #define MKD(N) DEFDEP(N, A_##N)
 DEPOPS(MKD)
+
+#define DEFMIX(NAME, ASMG)                                                                            \
+    __global__ void __launch_bounds__(1024) k_##NAME(unsigned long long *cyc, uint32_t *sink, int iters) { \
+        uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        uint32_t b = threadIdx.x * 3u + 7u, c = threadIdx.x ^ 0x55u;                                  \
+        __syncthreads();                                                                              \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
+        for (int i = 0; i < iters; ++i) {                                                             \
+            asm volatile(ASMG("%0") ASMG("%0") ASMG("%0") ASMG("%0")                                   \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)     \
+                         : "v"(b), "v"(c));                                                           \
+        }                                                                                             \
+        asm volatile("s_nop 0" ::: "memory");                                                         \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;          \
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;             \
+    }
+DEFMIX(MIXA, A_MIXA)
+DEFMIX(MIXB, A_MIXB)
+DEFMIX(MIXC, A_MIXC)
 
 typedef void (*kfn)(unsigned long long *, uint32_t *, int);
 struct Ent { const char *name; kfn fn; };
 #define ENT(N) {#N, k_##N},
 #define ENTD(N) {"dep_" #N, d_##N},
-static Ent ents[] = {OPS(ENT) DEPOPS(ENTD)};
+static Ent ents[] = {OPS(ENT) DEPOPS(ENTD) {"MIXA", k_MIXA}, {"MIXB", k_MIXB}, {"MIXC", k_MIXC}};
 
 int main() {
     hipDeviceProp_t prop;
