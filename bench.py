@@ -122,10 +122,17 @@ def main():
     dist_on = world > 1
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    # one rank per GPU; on a box with fewer GPUs than ranks (1-GPU rehearsal of the N > 1 path with
+    # MULUT_BENCH_BACKEND=gloo) ranks share devices
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("MULUT_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
 
     luts = load_lut_dict(os.path.join(ROOT, "tests", "golden", "luts"), STAGES, MODES, SCALE, 4, "LUT_ft")
     eng = MuLUTEngine(local).configure(STAGES, MODES, SCALE, 4).set_lut_dict(luts)

@@ -290,3 +290,37 @@ def test_full_1080p_frame(eng, shipped_luts):
     assert torch.equal(torch.cat(parts, 0), out[1])
     # determinism
     assert torch.equal(eng.pipeline(batch), out)
+
+
+# ---------------------------------------------------------------------------------------------
+# hipGraph capture (deep cascades are launch-bound at small frames; config 5 of BASELINE.json)
+# ---------------------------------------------------------------------------------------------
+def test_pipeline_replays_from_a_captured_graph():
+    stages, modes, scale = 4, "sdy", 2
+    e = MuLUTEngine(0).configure(stages, modes, scale, 4)
+    luts = {}
+    for s in range(stages):
+        for mode in modes:
+            luts["s%d_%s" % (s + 1, mode)] = synthetic_lut(31 * s + ord(mode), scale * scale if s + 1 == stages else 1)
+    e.set_lut_dict(luts)
+    img = np.random.default_rng(3).integers(0, 256, (2, 45, 77, 3), dtype=np.uint8)
+    x = dev(img)
+    out = torch.empty((2, 90, 154, 3), dtype=torch.uint8, device="cuda")
+    e.reserve(2, 45, 77, 3)                       # no allocation inside the captured region
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        e.pipeline(x, out=out)                    # warm-up: kernel attributes are set on first launch
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        e.pipeline(x, out=out)
+    want = np.stack([c_oracle.pipeline(luts, stages, modes, scale, im) for im in img])
+    for trial in range(2):
+        x.copy_(dev(np.roll(img, trial, axis=2)))
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ref = want if trial == 0 else np.stack([c_oracle.pipeline(luts, stages, modes, scale, im)
+                                                for im in np.roll(img, trial, axis=2)])
+        assert np.array_equal(out.cpu().numpy(), ref), trial
+    e.close()
