@@ -178,16 +178,19 @@ MULUT_HD void static_for(F &&f) {
 // Two passes of one site are processed side by side in the low / high half of a dword.  On the
 // GPU these compile to v_pk_*_u16 (one instruction for both halves); the host versions exist for
 // tests/host_emul only.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__clang__)
 typedef unsigned short mulut_u16x2 __attribute__((ext_vector_type(2)));
 #define MULUT_PK(x) __builtin_bit_cast(mulut_u16x2, (uint32_t)(x))
 #define MULUT_UNPK(v) __builtin_bit_cast(uint32_t, (v))
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
 MULUT_HD uint32_t pk_add(uint32_t a, uint32_t b) { return MULUT_UNPK(MULUT_PK(a) + MULUT_PK(b)); }
 MULUT_HD uint32_t pk_sub(uint32_t a, uint32_t b) { return MULUT_UNPK(MULUT_PK(a) - MULUT_PK(b)); }
 MULUT_HD uint32_t pk_min(uint32_t a, uint32_t b) { return MULUT_UNPK(__builtin_elementwise_min(MULUT_PK(a), MULUT_PK(b))); }
 MULUT_HD uint32_t pk_max(uint32_t a, uint32_t b) { return MULUT_UNPK(__builtin_elementwise_max(MULUT_PK(a), MULUT_PK(b))); }
 MULUT_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return MULUT_UNPK(MULUT_PK(a) * MULUT_PK(b) + MULUT_PK(c)); }
 MULUT_HD uint32_t pk_shr12(uint32_t a) { return MULUT_UNPK(MULUT_PK(a) >> (unsigned short)12); }
+MULUT_HD uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return MULUT_UNPK(__builtin_elementwise_sub_sat(MULUT_PK(a), MULUT_PK(b))); }
 #else
 MULUT_HD uint32_t pk_add(uint32_t a, uint32_t b) { return ((a + b) & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16); }
 MULUT_HD uint32_t pk_sub(uint32_t a, uint32_t b) { return ((a - b) & 0xFFFFu) | (((a >> 16) - (b >> 16)) << 16); }
@@ -205,6 +208,11 @@ MULUT_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
     return (((a & 0xFFFFu) * (b & 0xFFFFu) + (c & 0xFFFFu)) & 0xFFFFu) | ((((a >> 16) * (b >> 16) + (c >> 16)) & 0xFFFFu) << 16);
 }
 MULUT_HD uint32_t pk_shr12(uint32_t a) { return ((a & 0xFFFFu) >> 12) | (((a >> 16) >> 12) << 16); }
+MULUT_HD uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
+    const uint32_t l = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) - (b & 0xFFFFu) : 0u;
+    const uint32_t h = (a >> 16) > (b >> 16) ? (a >> 16) - (b >> 16) : 0u;
+    return l | (h << 16);
+}
 #endif
 MULUT_HD uint32_t pk_dup(uint32_t lo16) { return lo16 | (lo16 << 16); }
 MULUT_HD void pk_cmpx_desc(uint32_t &a, uint32_t &b) {
@@ -296,6 +304,47 @@ MULUT_HD void simplex4_band_pair(uint32_t va, uint32_t pb, uint32_t pc, uint32_t
     // in band <=> 16*(h - ha + 1) in {0,16,32} for b, c, d (out-of-range differences wrap to >= 0xFFF0 or reach 48+)
     const uint32_t off = pk_dup((16u - ha16) & 0xFFFFu);
     o.t_band = pk_max(pk_max(pk_add(hb16, off), pk_add(hc16, off)), pk_add(hd16, off));
+}
+
+// Pre-split pixel code used by the expanded-band kernel's image tile: the LSB nibble already sits where
+// the sort key wants it and the MSB nibble where the band offset math wants it,
+//      code(v) = (v & 15) << 12 | (v & 0xF0)            value(code) = (code >> 12) | (code & 0xF0)
+// so building a key is one v_and_or and the 16*h term one v_and on a packed pair of codes.
+MULUT_HD uint32_t pixel_code(uint32_t v) { return ((v & 15u) << 12) | (v & 0xF0u); }
+MULUT_HD int pixel_value(uint32_t code) { return (int)(((code >> 12) & 15u) | (code & 0xF0u)); }
+
+// simplex4_band_pair on pixel codes: ca = code of the anchor (low half only), pb/pc/pd = packed code pairs.
+// Outputs as simplex4_band_pair, except t_band holds saturate(max - 32) per half: a half is in band iff 0.
+MULUT_HD void simplex4_band_pair_code(uint32_t ca, uint32_t pb, uint32_t pc, uint32_t pd, BandPair &o) {
+    constexpr uint32_t RB = 16;
+    constexpr uint32_t SA = kBandStrideA * RB, SB = kBandStrideB * RB, SC = kBandStrideC * RB, SD = kBandStrideD * RB;
+    const uint32_t hb16 = pb & 0x00F000F0u, hc16 = pc & 0x00F000F0u, hd16 = pd & 0x00F000F0u;
+    const uint32_t ha16 = ca & 0xF0u;
+    uint32_t k0 = pk_dup((ca & 0xF000u) | SA);
+    uint32_t k1 = (pb & 0xF000F000u) | pk_dup(SB);
+    uint32_t k2 = (pc & 0xF000F000u) | pk_dup(SC);
+    uint32_t k3 = (pd & 0xF000F000u) | pk_dup(SD);
+    pk_cmpx_desc(k0, k1);
+    pk_cmpx_desc(k2, k3);
+    pk_cmpx_desc(k0, k2);
+    pk_cmpx_desc(k1, k3);
+    pk_cmpx_desc(k1, k2);
+    const uint32_t f1 = pk_shr12(k0), f2 = pk_shr12(k1), f3 = pk_shr12(k2), f4 = pk_shr12(k3);
+    const uint32_t base_a = pk_dup((ha16 * kBandStrideA) + kBandBase * RB);
+    const uint32_t base = pk_mad(hb16, pk_dup(kBandStrideB), pk_mad(hc16, pk_dup(kBandStrideC), pk_add(hd16, base_a)));
+    o.addr[0] = base;
+    o.addr[1] = pk_add(base, k0 & 0x0FFF0FFFu);
+    o.addr[2] = pk_add(o.addr[1], k1 & 0x0FFF0FFFu);
+    o.addr[3] = pk_add(o.addr[2], k2 & 0x0FFF0FFFu);
+    o.addr[4] = pk_add(base, pk_dup(kBandRowsPerA * RB));
+    o.w[0] = pk_sub(pk_dup(kQ), f1);
+    o.w[1] = pk_sub(f1, f2);
+    o.w[2] = pk_sub(f2, f3);
+    o.w[3] = pk_sub(f3, f4);
+    o.w[4] = f4;
+    const uint32_t off = pk_dup((16u - ha16) & 0xFFFFu);
+    const uint32_t t = pk_max(pk_max(pk_add(hb16, off), pk_add(hc16, off)), pk_add(hd16, off));
+    o.t_band = pk_sub_sat(t, pk_dup(32u));
 }
 
 // ---- merged rotation pairs ----------------------------------------------------------------------------

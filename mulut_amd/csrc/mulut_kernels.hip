@@ -108,6 +108,22 @@ __device__ __forceinline__ void load_tile(const StageArgs &a, int n, int y0, int
     }
 }
 
+// same tile, stored as 16-bit pixel codes (mulut_core.h pixel_code) for the expanded-band kernel
+template <int TW, int TH, int NT>
+__device__ __forceinline__ void load_tile_code(const StageArgs &a, int n, int y0, int x0, uint16_t *s_img) {
+    constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
+    const int total = a.C * PH * PW;
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    for (int i = threadIdx.x; i < total; i += NT) {
+        const int px = i % PW;
+        const int py = (i / PW) % PH;
+        const int c = i / (PW * PH);
+        const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
+        const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
+        s_img[i] = (uint16_t)pixel_code(*view_addr(a.in, n, c, gy, gx));
+    }
+}
+
 __device__ __forceinline__ void decode_tile(const StageArgs &a, int tile, int &n, int &y0, int &x0, int TW, int TH) {
     int b = tile;
     const int tx = b % a.tiles_x;
@@ -809,25 +825,31 @@ __device__ __forceinline__ void pass_global_lean(const void *lut, int va, int vb
 }
 
 template <int R>
-__device__ __forceinline__ void pair_x(const uint8_t *band, const void *lut, const uint8_t *ctr, int o0, int o1, int o2,
-                                       const StageArgs &a, RotAcc<4> &acc) {
-    const int va = ctr[0];
+__device__ __forceinline__ void pair_x(const uint8_t *band, const void *lut, const uint16_t *ctr, int o0, int o1, int o2,
+                                       RotAcc<4> &acc) {
+    // the tile holds pixel codes: a key is one v_and_or of a packed pair, the 16*h term one v_and
+    const uint32_t ca = ctr[0];
 #if MULUT_ABLATE == 8   /* timing-only: no neighbour reads, index math hoistable */
-    const int b0 = va, b1 = va, c0 = va, c1 = va, d0 = va, d1 = va;
+    const uint32_t pb = ca * 0x10001u, pc = pb, pd = pb;
     (void)o0; (void)o1; (void)o2;
 #else
-    const int b0 = ctr[o0], b1 = ctr[-o0], c0 = ctr[o1], c1 = ctr[-o1], d0 = ctr[o2], d1 = ctr[-o2];
+    // (ds_read_u16_d16_hi cannot be used to fill the high half directly: with SRAM-ECC on, as on this part,
+    // d16 loads zero the other half of the destination)
+    const uint32_t pb = ctr[o0] | ((uint32_t)ctr[-o0] << 16);
+    const uint32_t pc = ctr[o1] | ((uint32_t)ctr[-o1] << 16);
+    const uint32_t pd = ctr[o2] | ((uint32_t)ctr[-o2] << 16);
 #endif
     BandPair bp;
-    simplex4_band_pair((uint32_t)va, (uint32_t)b0 | ((uint32_t)b1 << 16), (uint32_t)c0 | ((uint32_t)c1 << 16),
-                       (uint32_t)d0 | ((uint32_t)d1 << 16), bp);
-    const bool inA = (bp.t_band & 0xFFFFu) <= 32u, inB = (bp.t_band >> 16) <= 32u;
-    if (__all(inA & inB)) {
+    simplex4_band_pair_code(ca, pb, pc, pd, bp);
+    if (__all(bp.t_band == 0u)) {          // both passes in band in every lane
         rows_x<R, 0>(band, bp, acc);
         rows_x<R + 2, 1>(band, bp, acc);
     } else {
-        if (inA) rows_x<R, 0>(band, bp, acc); else pass_global_lean<R>(lut, va, b0, c0, d0, acc);
-        if (inB) rows_x<R + 2, 1>(band, bp, acc); else pass_global_lean<R + 2>(lut, va, b1, c1, d1, acc);
+        const int va = pixel_value(ca);
+        if ((bp.t_band & 0xFFFFu) == 0u) rows_x<R, 0>(band, bp, acc);
+        else pass_global_lean<R>(lut, va, pixel_value(pb & 0xFFFFu), pixel_value(pc & 0xFFFFu), pixel_value(pd & 0xFFFFu), acc);
+        if ((bp.t_band >> 16) == 0u) rows_x<R + 2, 1>(band, bp, acc);
+        else pass_global_lean<R + 2>(lut, va, pixel_value(pb >> 16), pixel_value(pc >> 16), pixel_value(pd >> 16), acc);
     }
 }
 
@@ -836,7 +858,7 @@ __global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandAr
     constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
     constexpr int NT = TW * TH;
     constexpr int U = 4;
-    constexpr int kTileBytes = ((3 * PH * PW + 15) / 16) * 16;
+    constexpr int kTileBytes = ((2 * 3 * PH * PW + 15) / 16) * 16;   // 16-bit pixel codes
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_band = smem;                       // two buffers of kBandXBytes
     uint8_t *s_tile = smem + 2 * kBandXBytes;     // two buffers of kTileBytes
@@ -855,11 +877,11 @@ __global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandAr
     for (int tile = first, it = 0; tile < last; tile += step, ++it) {
         int n, y0, x0;
         decode_tile(a, tile, n, y0, x0, TW, TH);
-        uint8_t *s_img = s_tile + (it & 1) * kTileBytes;
-        load_tile<TW, TH, NT>(a, n, y0, x0, s_img);   // the buffer last read two tiles ago
+        uint16_t *s_img = (uint16_t *)(s_tile + (it & 1) * kTileBytes);
+        load_tile_code<TW, TH, NT>(a, n, y0, x0, s_img);   // the buffer last read two tiles ago
         const int y = y0 + ty, x = x0 + tx;
         const bool valid = y < a.oy1 && x < a.W;
-        const uint8_t *ctr = s_img + (ty + kHalo) * PW + (tx + kHalo);
+        const uint16_t *ctr = s_img + (ty + kHalo) * PW + (tx + kHalo);
         RotAcc<4> acc0, acc1, acc2;
         acc0.clear(); acc1.clear(); acc2.clear();
         for (int mv = 0; mv < a.M; ++mv, ++phase) {
@@ -890,15 +912,15 @@ __global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandAr
                 sample_offset(1, a.di[m][0], a.dj[m][0], dy, dx); const int q0 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
                 sample_offset(1, a.di[m][1], a.dj[m][1], dy, dx); const int q1 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
                 sample_offset(1, a.di[m][2], a.dj[m][2], dy, dx); const int q2 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
-                pair_x<0>(band, lut, ctr, p0, p1, p2, a, acc0);
-                pair_x<1>(band, lut, ctr, q0, q1, q2, a, acc0);
+                pair_x<0>(band, lut, ctr, p0, p1, p2, acc0);
+                pair_x<1>(band, lut, ctr, q0, q1, q2, acc0);
                 if (a.C > 1) {
-                    pair_x<0>(band, lut, ctr + PH * PW, p0, p1, p2, a, acc1);
-                    pair_x<1>(band, lut, ctr + PH * PW, q0, q1, q2, a, acc1);
+                    pair_x<0>(band, lut, ctr + PH * PW, p0, p1, p2, acc1);
+                    pair_x<1>(band, lut, ctr + PH * PW, q0, q1, q2, acc1);
                 }
                 if (a.C > 2) {
-                    pair_x<0>(band, lut, ctr + 2 * PH * PW, p0, p1, p2, a, acc2);
-                    pair_x<1>(band, lut, ctr + 2 * PH * PW, q0, q1, q2, a, acc2);
+                    pair_x<0>(band, lut, ctr + 2 * PH * PW, p0, p1, p2, acc2);
+                    pair_x<1>(band, lut, ctr + 2 * PH * PW, q0, q1, q2, acc2);
                 }
             }
         }
@@ -923,7 +945,7 @@ const char *stage_bandx_name(int out_mode) {
 template <int OUT>
 static hipError_t launch_bandx_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
     auto kern = stage_bandx_kernel<OUT, KB_TW, KB_TH>;
-    const size_t lds = 2 * (size_t)kBandXBytes + 2 * (size_t)(((3 * (KB_TH + 2 * kHalo) * (KB_TW + 2 * kHalo) + 15) / 16) * 16);
+    const size_t lds = 2 * (size_t)kBandXBytes + 2 * (size_t)(((2 * 3 * (KB_TH + 2 * kHalo) * (KB_TW + 2 * kHalo) + 15) / 16) * 16);
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;

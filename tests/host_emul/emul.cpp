@@ -120,6 +120,16 @@ extern "C" long emul_check_band_pair(int step) {
                     BandPair bp;
                     simplex4_band_pair((uint32_t)va, (uint32_t)vb | ((uint32_t)vb2 << 16), (uint32_t)vc | ((uint32_t)vc2 << 16),
                                        (uint32_t)vd | ((uint32_t)vd2 << 16), bp);
+                    {   // the pixel-code form must agree with the value form in every output
+                        BandPair bc;
+                        simplex4_band_pair_code(pixel_code(va), pixel_code(vb) | (pixel_code(vb2) << 16),
+                                                pixel_code(vc) | (pixel_code(vc2) << 16), pixel_code(vd) | (pixel_code(vd2) << 16), bc);
+                        for (int j = 0; j < 5; ++j)
+                            if (bc.addr[j] != bp.addr[j] || bc.w[j] != bp.w[j]) ++bad;
+                        if (((bc.t_band & 0xFFFFu) == 0) != ((bp.t_band & 0xFFFFu) <= 32u)) ++bad;
+                        if (((bc.t_band >> 16) == 0) != ((bp.t_band >> 16) <= 32u)) ++bad;
+                        if (pixel_value(pixel_code(va)) != va) ++bad;
+                    }
                     for (int half = 0; half < 2; ++half) {
                         const int b = half ? vb2 : vb, c = half ? vc2 : vc, d = half ? vd2 : vd;
                         int idx[5], w[5];
