@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(NT) stage_u1_kernel(StageArgs a) {
     }
 }
 
-constexpr int K1_TW = 64, K1_TH = 32, K1_NT = 1024, K1_SPT = 6;  // 3 ch * 64*32 / 1024 = 6
+constexpr int K1_TW = 64, K1_TH = 64, K1_NT = 1024, K1_SPT = 12;  // 3 ch * 64*64 / 1024 = 12
 static_assert(K1_SPT * K1_NT >= 3 * K1_TW * K1_TH, "SPT too small for 3 channels");
 
 void stage_u1_tile(int &tw, int &th) { tw = K1_TW; th = K1_TH; }
