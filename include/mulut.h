@@ -117,6 +117,21 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C);
 int mulut_set_stage_timing(mulut_ctx *ctx, int enable);
 int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap);
 
+/* ---- LUT-aware fine-tuning (the differentiable twin; stateless, float32) -----------------------------
+ * One stage of MuLUT.forward (sr/model.py:289-312) = InterpTorchBatch (:69-287) over all modes x 4 rotations
+ * with the per-pass BPDA rounding (:308) and the stage's clamp/round (:309).
+ *   weights_q : M device pointers, the QUANTISED tables clamp(round(w*127),-127,127) as float32 [83521][u*u]
+ *               (sr/model.py:74-76 -- done by the caller, which also applies that step's backward)
+ *   x         : device float32 [B][C][H][W] in 0..255 (the module multiplies its input by 255, :290)
+ *   out       : device float32 [B][C][H*u][W*u] in 0..255
+ * backward: grad_out = dL/d out; accumulates dL/d weights_q into grad_wq[m] (atomic adds; zero them first) and
+ * dL/dx into grad_x (zero it first).  u = upscale for the last stage, else 1. */
+int mulut_ft_stage_forward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                           int B, int C, int H, int W, float *out, void *stream);
+int mulut_ft_stage_backward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                            const float *grad_out, int B, int C, int H, int W, float *const *grad_wq, float *grad_x,
+                            void *stream);
+
 /* Tuning knobs (never change results).  "final_stage_kernel": 0 = auto, 1 = full-table gather
  * kernel, 2 = compact LDS-band kernel, 3 = expanded LDS-band kernel (2, 3: scale 4, <= 3 modes).  Unknown key or value: MULUT_EINVAL. */
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value);

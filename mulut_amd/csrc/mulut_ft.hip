@@ -1,0 +1,272 @@
+// mulut_ft.hip -- LUT-aware fine-tuning kernels: the differentiable twin of the inference path.
+//
+// Reference: MuLUT.InterpTorchBatch + MuLUT.forward, sr/model.py:69-312 (driver sr/3_finetune_lut.py).
+// One kernel pair per STAGE:
+//   ft_stage_fwd  per LR site and channel: all modes x 4 rotations; each pass is the reference's float32
+//                 expression  ((((q-f1)*p0 + (f1-f2)*p1) + (f2-f3)*p2) + (f3-f4)*p3) + f4*p4, /q  (no FMA
+//                 contraction), accumulated as  pred = round(pred + pass)  after EVERY pass (:308), then
+//                 x = round(clamp(pred/avg + bias, 0, 255)) (:309).
+//   ft_stage_bwd  recomputes the stage forward (for the clamp mask), then scatters
+//                   d/d(table row j)  = w_j/q * g            (atomic add into the quantised-table gradient)
+//                   d/d(f of rank j)  = sum_e g*(p_j - p_{j-1})/q   (atomic add into the input gradient at
+//                                       the clamped source pixel: replicate-pad and rot90 backward)
+//                 rounding is BPDA identity (:59-67), clamp passes gradient inside [0,255] inclusive.
+// The simplex case at TIES is the reference's 24-branch cascade with strict '>' (:191-282): forward
+// values do not depend on it, gradients do.
+// Tables are passed already quantised (clamp(round(w*127),-127,127), :74-76) by the Python module, which
+// also applies that step's backward (x127, clamp mask).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "../../include/mulut.h"
+#include "mulut_core.h"
+
+#pragma clang fp contract(off)
+
+namespace mulut {
+
+constexpr int kMaxFtModes = MULUT_MAX_MODES;
+
+struct FtArgs {
+    const float *w[kMaxFtModes];
+    float *gw[kMaxFtModes];
+    const float *x;     // [B][C][H][W], values 0..255
+    const float *gout;  // [B][C][H*u][W*u]
+    float *out;         // [B][C][H*u][W*u]
+    float *gx;          // [B][C][H][W]
+    int B, C, H, W, u, M, is_last;
+    int di[kMaxFtModes][3], dj[kMaxFtModes][3];
+};
+
+// the reference's tie-breaking: dimension ids (0=a,1=b,2=c,3=d) in descending order of f
+__device__ __forceinline__ void ft_order(float fa, float fb, float fc, float fd, int (&o)[4]) {
+    const bool fab = fa > fb, fac = fa > fc, fad = fa > fd, fbc = fb > fc, fbd = fb > fd, fcd = fc > fd;
+    int code;   // four 2-bit ids, first in the low bits
+#define ORD(p, q, r, s) ((p) | ((q) << 2) | ((r) << 4) | ((s) << 6))
+    if (fab && fbc) code = fcd ? ORD(0, 1, 2, 3) : fbd ? ORD(0, 1, 3, 2) : fad ? ORD(0, 3, 1, 2) : ORD(3, 0, 1, 2);
+    else if (fab && fac) code = fbd ? ORD(0, 2, 1, 3) : fcd ? ORD(0, 2, 3, 1) : fad ? ORD(0, 3, 2, 1) : ORD(3, 0, 2, 1);
+    else if (fab) code = fbd ? ORD(2, 0, 1, 3) : fad ? ORD(2, 0, 3, 1) : fcd ? ORD(2, 3, 0, 1) : ORD(3, 2, 0, 1);
+    else if (fac) code = fcd ? ORD(1, 0, 2, 3) : fad ? ORD(1, 0, 3, 2) : fbd ? ORD(1, 3, 0, 2) : ORD(3, 1, 0, 2);
+    else if (fbc) code = fad ? ORD(1, 2, 0, 3) : fcd ? ORD(1, 2, 3, 0) : fbd ? ORD(1, 3, 2, 0) : ORD(3, 1, 2, 0);
+    else code = fad ? ORD(2, 1, 0, 3) : fbd ? ORD(2, 1, 3, 0) : fcd ? ORD(2, 3, 1, 0) : ORD(3, 2, 1, 0);
+#undef ORD
+    o[0] = code & 3; o[1] = (code >> 2) & 3; o[2] = (code >> 4) & 3; o[3] = (code >> 6) & 3;
+}
+
+struct FtPass {
+    int idx[5];      // table rows of the five vertices
+    float wt[5];     // q-f1, f1-f2, f2-f3, f3-f4, f4
+    int src[4];      // flat pixel index (within the channel plane) of the key of rank j
+};
+
+__device__ __forceinline__ void ft_pass_setup(const float *plane, int H, int W, int y, int x, int r, const int (&di)[3],
+                                              const int (&dj)[3], FtPass &p) {
+    int pix[4];
+    float v[4];
+    pix[0] = y * W + x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int dy, dx;
+        sample_offset(r, di[k], dj[k], dy, dx);
+        pix[k + 1] = imin(imax(y + dy, 0), H - 1) * W + imin(imax(x + dx, 0), W - 1);
+    }
+    int h[4];
+    float f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = plane[pix[k]];
+        const float hf = floorf(v[k] / (float)kQ);       // torch.floor_divide(img, q)
+        h[k] = (int)hf;
+        f[k] = v[k] - (float)kQ * hf;                    // img % q
+    }
+    int o[4];
+    ft_order(f[0], f[1], f[2], f[3], o);
+    const int stride[4] = {kStrideA, kStrideB, kStrideC, kStrideD};
+    float fs[4];
+    int ss[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // select without dynamic register indexing
+        const int d = o[j];
+        fs[j] = d == 0 ? f[0] : d == 1 ? f[1] : d == 2 ? f[2] : f[3];
+        ss[j] = d == 0 ? stride[0] : d == 1 ? stride[1] : d == 2 ? stride[2] : stride[3];
+        p.src[j] = d == 0 ? pix[0] : d == 1 ? pix[1] : d == 2 ? pix[2] : pix[3];
+    }
+    p.idx[0] = h[0] * kStrideA + h[1] * kStrideB + h[2] * kStrideC + h[3];
+    p.idx[1] = p.idx[0] + ss[0];
+    p.idx[2] = p.idx[1] + ss[1];
+    p.idx[3] = p.idx[2] + ss[2];
+    p.idx[4] = p.idx[3] + ss[3];
+    p.wt[0] = (float)kQ - fs[0];
+    p.wt[1] = fs[0] - fs[1];
+    p.wt[2] = fs[1] - fs[2];
+    p.wt[3] = fs[2] - fs[3];
+    p.wt[4] = fs[3];
+}
+
+// pred after all passes of the stage for one site (the order of additions and roundings is the reference's)
+template <int U>
+__device__ __forceinline__ void ft_site_forward(const FtArgs &a, const float *plane, int y, int x, float (&pred)[U * U]) {
+#pragma unroll
+    for (int e = 0; e < U * U; ++e) pred[e] = 0.0f;
+    for (int m = 0; m < a.M; ++m) {
+        const float *tab = a.w[m];
+        const int di[3] = {a.di[m][0], a.di[m][1], a.di[m][2]}, dj[3] = {a.dj[m][0], a.dj[m][1], a.dj[m][2]};
+        static_for<0, 4>([&](auto R) {
+            constexpr int r = R;
+            FtPass p;
+            ft_pass_setup(plane, a.H, a.W, y, x, r, di, dj, p);
+            const float *r0 = tab + (long long)p.idx[0] * (U * U), *r1 = tab + (long long)p.idx[1] * (U * U);
+            const float *r2 = tab + (long long)p.idx[2] * (U * U), *r3 = tab + (long long)p.idx[3] * (U * U);
+            const float *r4 = tab + (long long)p.idx[4] * (U * U);
+            static_for<0, U * U>([&](auto E) {
+                constexpr int eo = E;                                   // block position sy*U+sx
+                constexpr int e = row_elem(r, eo / U, eo % U, U);       // table element landing there
+                const float val = ((((p.wt[0] * r0[e] + p.wt[1] * r1[e]) + p.wt[2] * r2[e]) + p.wt[3] * r3[e]) + p.wt[4] * r4[e]) /
+                                  (float)kQ;
+                pred[eo] = rintf(pred[eo] + val);                       // pred += ...; pred = round_func(pred)
+            });
+        });
+    }
+}
+
+template <int U>
+__global__ void __launch_bounds__(256) ft_stage_fwd(FtArgs a) {
+    const long long nsite = (long long)a.B * a.C * a.H * a.W;
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsite) return;
+    const int x = (int)(s % a.W), y = (int)((s / a.W) % a.H);
+    const long long bc = s / ((long long)a.W * a.H);
+    const float *plane = a.x + bc * a.H * a.W;
+    float pred[U * U];
+    ft_site_forward<U>(a, plane, y, x, pred);
+    const float avg = a.is_last ? (float)a.M : (float)(4 * a.M), bias = a.is_last ? 0.0f : 127.0f;
+    float *po = a.out + bc * (long long)(a.H * U) * (a.W * U);
+    static_for<0, U * U>([&](auto E) {
+        constexpr int eo = E;
+        const float t = fminf(fmaxf(pred[eo] / avg + bias, 0.0f), 255.0f);
+        po[(long long)(y * U + eo / U) * (a.W * U) + (x * U + eo % U)] = rintf(t);
+    });
+}
+
+template <int U>
+__global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
+    const long long nsite = (long long)a.B * a.C * a.H * a.W;
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsite) return;
+    const int x = (int)(s % a.W), y = (int)((s / a.W) % a.H);
+    const long long bc = s / ((long long)a.W * a.H);
+    const float *plane = a.x + bc * a.H * a.W;
+    float *gplane = a.gx + bc * a.H * a.W;
+    float g[U * U];
+    {
+        float pred[U * U];
+        ft_site_forward<U>(a, plane, y, x, pred);
+        const float avg = a.is_last ? (float)a.M : (float)(4 * a.M), bias = a.is_last ? 0.0f : 127.0f;
+        const float *pg = a.gout + bc * (long long)(a.H * U) * (a.W * U);
+        static_for<0, U * U>([&](auto E) {
+            constexpr int eo = E;
+            const float t = pred[eo] / avg + bias;
+            const float go = pg[(long long)(y * U + eo / U) * (a.W * U) + (x * U + eo % U)];
+            g[eo] = (t >= 0.0f && t <= 255.0f) ? go / avg : 0.0f;   // clamp backward, then d(pred/avg)
+        });
+    }
+    for (int m = 0; m < a.M; ++m) {
+        const float *tab = a.w[m];
+        float *gtab = a.gw[m];
+        const int di[3] = {a.di[m][0], a.di[m][1], a.di[m][2]}, dj[3] = {a.dj[m][0], a.dj[m][1], a.dj[m][2]};
+        static_for<0, 4>([&](auto R) {
+            constexpr int r = R;
+            FtPass p;
+            ft_pass_setup(plane, a.H, a.W, y, x, r, di, dj, p);
+            float dsum[5];   // sum_e g * p_j[e]
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float *row = tab + (long long)p.idx[j] * (U * U);
+                float *grow = gtab + (long long)p.idx[j] * (U * U);
+                const float wq = p.wt[j] / (float)kQ;
+                float acc = 0.0f;
+                static_for<0, U * U>([&](auto E) {
+                    constexpr int eo = E;
+                    constexpr int e = row_elem(r, eo / U, eo % U, U);
+                    acc += g[eo] * row[e];
+                    if (wq != 0.0f && g[eo] != 0.0f) atomicAdd(&grow[e], wq * g[eo]);
+                });
+                dsum[j] = acc;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {   // d/d f of rank j+1 = (p_{j+1} - p_j) . g / q
+                const float df = (dsum[j + 1] - dsum[j]) / (float)kQ;
+                if (df != 0.0f) atomicAdd(&gplane[p.src[j]], df);
+            }
+        });
+    }
+}
+
+template <int U>
+static hipError_t launch_ft(const FtArgs &a, bool backward, hipStream_t st) {
+    const long long nsite = (long long)a.B * a.C * a.H * a.W;
+    const long long nb = (nsite + 255) / 256;
+    if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (backward) hipLaunchKernelGGL(ft_stage_bwd<U>, dim3((unsigned)nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(ft_stage_fwd<U>, dim3((unsigned)nb), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace mulut
+
+using namespace mulut;
+
+static int ft_fill(FtArgs &a, const float *const *weights, float *const *grad_wq, const char *modes, int is_last, int u,
+                   const float *x, int B, int C, int H, int W) {
+    if (!weights || !modes || !x || B <= 0 || C <= 0 || H <= 0 || W <= 0) return MULUT_EINVAL;
+    const size_t M = strlen(modes);
+    if (M < 1 || M > (size_t)kMaxFtModes || u < 1 || u > 4) return MULUT_EUNSUPPORTED;
+    memset(&a, 0, sizeof(a));
+    for (size_t m = 0; m < M; ++m) {
+        int di[3], dj[3];
+        if (!pattern_offsets(modes[m], di, dj)) return MULUT_EMODE;
+        if (!weights[m] || (grad_wq && !grad_wq[m])) return MULUT_EINVAL;
+        a.w[m] = weights[m];
+        a.gw[m] = grad_wq ? grad_wq[m] : nullptr;
+        for (int k = 0; k < 3; ++k) {
+            a.di[m][k] = di[k];
+            a.dj[m][k] = dj[k];
+        }
+    }
+    a.x = x;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.u = u; a.M = (int)M; a.is_last = is_last ? 1 : 0;
+    return MULUT_OK;
+}
+
+extern "C" {
+
+int mulut_ft_stage_forward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                           int B, int C, int H, int W, float *out, void *stream) {
+    FtArgs a;
+    int rc = ft_fill(a, weights_q, nullptr, modes, is_last, u, x, B, C, H, W);
+    if (rc) return rc;
+    if (!out) return MULUT_EINVAL;
+    a.out = out;
+    if (hipSetDevice(device) != hipSuccess) return MULUT_ENODEVICE;
+    hipError_t e = u == 1 ? launch_ft<1>(a, false, (hipStream_t)stream) : u == 2 ? launch_ft<2>(a, false, (hipStream_t)stream)
+                 : u == 3 ? launch_ft<3>(a, false, (hipStream_t)stream) : launch_ft<4>(a, false, (hipStream_t)stream);
+    return e == hipSuccess ? MULUT_OK : MULUT_EHIP;
+}
+
+int mulut_ft_stage_backward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                            const float *grad_out, int B, int C, int H, int W, float *const *grad_wq, float *grad_x,
+                            void *stream) {
+    FtArgs a;
+    int rc = ft_fill(a, weights_q, grad_wq, modes, is_last, u, x, B, C, H, W);
+    if (rc) return rc;
+    if (!grad_out || !grad_wq || !grad_x) return MULUT_EINVAL;
+    a.gout = grad_out;
+    a.gx = grad_x;
+    if (hipSetDevice(device) != hipSuccess) return MULUT_ENODEVICE;
+    hipError_t e = u == 1 ? launch_ft<1>(a, true, (hipStream_t)stream) : u == 2 ? launch_ft<2>(a, true, (hipStream_t)stream)
+                 : u == 3 ? launch_ft<3>(a, true, (hipStream_t)stream) : launch_ft<4>(a, true, (hipStream_t)stream);
+    return e == hipSuccess ? MULUT_OK : MULUT_EHIP;
+}
+
+}  // extern "C"

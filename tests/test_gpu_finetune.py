@@ -1,0 +1,85 @@
+"""GPU parity of the fine-tune kernels against fixtures produced by running the
+reference's MuLUT module (sr/model.py) on CPU (tests/golden/gen_golden_ft.py): forward within 1e-5,
+loss and all parameter / input gradients within float-accumulation tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def synthetic_lut(seed, vnum):
+    rng = np.random.default_rng(seed)
+    return rng.integers(-127, 128, size=(17 ** 4, vnum), dtype=np.int8)
+
+
+def build_module(tmp_path, fx, name):
+    from mulut_amd.finetune import MuLUT
+    stages, scale = [int(v) for v in fx[name + "/cfg"]]
+    modes = bytes(fx[name + "/modes"]).decode()
+    src = bytes(fx[name + "/lutsrc"]).decode()
+    d = tmp_path / name
+    d.mkdir()
+    for s in range(stages):
+        vnum = scale * scale if s + 1 == stages else 1
+        for m in modes:
+            key = "s%d_%s" % (s + 1, m)
+            if src == "shipped":
+                t = np.load(os.path.join(GOLDEN, "luts", "LUT_ft_x4_4bit_int8_%s.npy" % key)).reshape(-1, vnum)
+            elif src == "s2_s":
+                t = np.load(os.path.join(GOLDEN, "luts", "LUT_ft_x4_4bit_int8_s2_s.npy")).reshape(-1, 16)
+            else:
+                t = synthetic_lut(17 * s + ord(m), vnum)
+            np.save(d / ("LUT_x%d_4bit_int8_%s.npy" % (scale, key)), t.astype(np.int8))
+    return MuLUT(str(d), stages, modes, upscale=scale, interval=4).cuda(), stages, modes
+
+
+@pytest.mark.parametrize("name", ["A_s2sdy_x4_u8", "B_s1s_x4_float", "C_s2sd_x2_u8", "D_s2sdy_x4_float"])
+def test_forward_and_gradients_match_reference(tmp_path, name):
+    fx = np.load(os.path.join(GOLDEN, "ft_fixtures.npz"))
+    net, stages, modes = build_module(tmp_path, fx, name)
+    x = torch.from_numpy(fx[name + "/x"]).cuda().requires_grad_(True)
+    y = net(x)
+    want = fx[name + "/y"]
+    got = y.detach().cpu().numpy()
+    # values are k/255; a mismatch would be >= 1/255, so 1e-5 means "the same rounding decisions everywhere"
+    assert np.abs(got - want).max() <= 1e-5, float(np.abs(got - want).max())
+    loss = torch.nn.functional.mse_loss(y, torch.from_numpy(fx[name + "/target"]).cuda())
+    assert abs(loss.item() - float(fx[name + "/loss"])) <= 1e-6
+    loss.backward()
+    gx = x.grad.cpu().numpy()
+    assert np.allclose(gx, fx[name + "/grad_x"], rtol=2e-4, atol=1e-7), float(np.abs(gx - fx[name + "/grad_x"]).max())
+    for s in range(stages):
+        for m in modes:
+            key = "s%d_%s" % (s + 1, m)
+            g = getattr(net, "weight_" + key).grad.cpu().numpy()
+            rows = fx[name + "/grad/" + key + "/rows"]
+            vals = fx[name + "/grad/" + key + "/vals"]
+            dense = np.zeros_like(g)
+            dense[rows] = vals
+            assert np.allclose(g, dense, rtol=2e-4, atol=1e-7), (key, float(np.abs(g - dense).max()))
+
+
+def test_module_contract(tmp_path):
+    fx = np.load(os.path.join(GOLDEN, "ft_fixtures.npz"))
+    net, stages, modes = build_module(tmp_path, fx, "A_s2sdy_x4_u8")
+    names = sorted(n for n, _ in net.named_parameters())
+    assert names == sorted("weight_s%d_%s" % (s, m) for s in (1, 2) for m in "sdy")      # sr/model.py:57
+    assert net.weight_s2_d.shape == (83521, 16) and net.weight_s1_s.shape == (83521, 1)
+    exp = net.export_int8()                                                               # sr/3_finetune_lut.py:162-169
+    ref = np.load(os.path.join(GOLDEN, "luts", "LUT_ft_x4_4bit_int8_s2_d.npy")).reshape(-1, 16)
+    assert exp["s2_d"].dtype == np.int8 and np.array_equal(exp["s2_d"], ref)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 1, 4, 4))          # CPU tensor: no CPU path
+    # one Adam step runs and changes the tables
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    x = torch.rand(4, 1, 16, 16, device="cuda")
+    loss = torch.nn.functional.mse_loss(net(x), torch.rand(4, 1, 64, 64, device="cuda"))
+    loss.backward()
+    before = net.weight_s2_s.detach().clone()
+    opt.step()
+    assert not torch.equal(before, net.weight_s2_s.detach())
