@@ -7,5 +7,6 @@ through libmulut_hip.so and raises if it (or a GPU) is missing.
 from .lut_io import lut_file_name, load_lut_dict, synthetic_lut  # noqa: F401
 from .engine import MuLUTEngine, MuLUTError  # noqa: F401
 from .interp import FourSimplexInterpFaster  # noqa: F401
+from . import finetune_lut  # noqa: F401
 
 __version__ = "0.1.0"

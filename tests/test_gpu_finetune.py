@@ -83,3 +83,28 @@ def test_module_contract(tmp_path):
     before = net.weight_s2_s.detach().clone()
     opt.step()
     assert not torch.equal(before, net.weight_s2_s.detach())
+
+
+def test_finetune_driver_reduces_loss_and_writes_luts(tmp_path):
+    """The driver twin (sr/3_finetune_lut.py) on the Set5 pairs: loss goes down, LUT_ft files appear in the
+    reference's int8 format and load back into the inference engine."""
+    from mulut_amd import finetune_lut, MuLUTEngine, load_lut_dict
+    exp = tmp_path / "exp"
+    exp.mkdir()
+    for s in (1, 2):
+        for m in "sdy":
+            t = np.load(os.path.join(GOLDEN, "luts", "LUT_ft_x4_4bit_int8_s%d_%s.npy" % (s, m)))
+            # start from a perturbed copy so there is something to learn
+            rng = np.random.default_rng(s * 7 + ord(m))
+            noisy = np.clip(t.astype(np.int32) + rng.integers(-12, 13, t.shape), -127, 127).astype(np.int8)
+            np.save(exp / ("LUT_x4_4bit_int8_s%d_%s.npy" % (s, m)), noisy)
+    losses = finetune_lut.main(["--stages", "2", "--modes", "sdy", "-e", str(exp), "--trainDir", os.path.join(GOLDEN, "Set5"),
+                                "--batchSize", "16", "--cropSize", "24", "--totalIter", "60", "--displayStep", "20",
+                                "--lr0", "1e-3", "--seed", "0"])
+    assert np.mean(losses[-15:]) < np.mean(losses[:15])
+    luts = load_lut_dict(str(exp), 2, "sdy", 4, 4, "LUT_ft")
+    assert luts["s2_y"].dtype == np.int8 and luts["s2_y"].shape == (83521, 16)
+    eng = MuLUTEngine(0).configure(2, "sdy", 4, 4).set_lut_dict(luts)
+    out = eng.pipeline(torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda"))
+    assert out.shape == (32, 32, 3)
+    eng.close()
