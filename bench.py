@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--lr-h", type=int, default=1080)
     ap.add_argument("--lr-w", type=int, default=1920)
     ap.add_argument("--dist", choices=["natural", "noise"], default="natural")
-    ap.add_argument("--cpu-crop", type=int, default=256, help="window edge for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-crop", type=int, default=512, help="window edge for the CPU baseline (0 = skip)")
     ap.add_argument("--skip-other", action="store_true", help="do not also time the other input distribution")
     ap.add_argument("--shard", choices=["frames", "strips"], default="frames",
                     help="frames: each GPU owns whole frames, no collective (default); strips: every frame is cut "
