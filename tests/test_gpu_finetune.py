@@ -108,3 +108,42 @@ def test_finetune_driver_reduces_loss_and_writes_luts(tmp_path):
     out = eng.pipeline(torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda"))
     assert out.shape == (32, 32, 3)
     eng.close()
+
+
+@pytest.mark.parametrize("stages,modes,scale,shape,kind", [
+    (1, "y", 4, (2, 3, 5, 7), "u8"), (2, "sdy", 4, (1, 1, 1, 1), "u8"), (3, "sd", 2, (2, 1, 9, 6), "float"),
+    (2, "dy", 3, (1, 2, 6, 8), "u8"), (2, "sdy", 4, (1, 1, 10, 10), "extreme"), (2, "s", 1, (1, 1, 7, 5), "float")])
+def test_more_shapes_vs_cpu_oracle(tmp_path, stages, modes, scale, shape, kind):
+    """GPU module vs the pinned CPU oracle (oracle/ft_torch.py) on shapes / configurations the fixtures do not hold."""
+    from mulut_amd.finetune import MuLUT
+    from oracle import ft_torch
+    rng = np.random.default_rng(stages * 100 + scale * 10 + len(modes))
+    tabs = {}
+    for s in range(stages):
+        vnum = scale * scale if s + 1 == stages else 1
+        for m in modes:
+            t = synthetic_lut(3 * s + ord(m), vnum)
+            tabs["s%d_%s" % (s + 1, m)] = t
+            np.save(tmp_path / ("LUT_x%d_4bit_int8_s%d_%s.npy" % (scale, s + 1, m)), t)
+    if kind == "u8":
+        x = rng.integers(0, 256, shape).astype(np.float32) / np.float32(255)
+    elif kind == "extreme":
+        x = rng.choice(np.array([0, 15, 16, 240, 255], np.float32), shape) / np.float32(255)
+    else:
+        x = rng.random(shape, dtype=np.float32)
+    tgt = rng.random((shape[0], shape[1], shape[2] * scale, shape[3] * scale), dtype=np.float32)
+    # CPU oracle
+    wcpu = {k: torch.from_numpy(v.astype(np.float32) / 127.0).requires_grad_(True) for k, v in tabs.items()}
+    xc = torch.from_numpy(x).requires_grad_(True)
+    yc = ft_torch.forward(wcpu, xc, stages, modes, scale)
+    torch.nn.functional.mse_loss(yc, torch.from_numpy(tgt)).backward()
+    # GPU module
+    net = MuLUT(str(tmp_path), stages, modes, upscale=scale, interval=4).cuda()
+    xg = torch.from_numpy(x).cuda().requires_grad_(True)
+    yg = net(xg)
+    torch.nn.functional.mse_loss(yg, torch.from_numpy(tgt).cuda()).backward()
+    assert np.abs(yg.detach().cpu().numpy() - yc.detach().numpy()).max() <= 1e-5
+    assert np.allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=2e-4, atol=1e-7)
+    for k, w in wcpu.items():
+        g = getattr(net, "weight_" + k).grad.cpu().numpy()
+        assert np.allclose(g, w.grad.numpy(), rtol=2e-4, atol=1e-7), k
