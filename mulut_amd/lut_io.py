@@ -43,3 +43,35 @@ def synthetic_lut(seed, vnum):
     """Seeded int8 table for configurations no shipped LUT exists for (deep cascades, x2, ...)."""
     rng = np.random.default_rng(seed)
     return rng.integers(-127, 128, size=(L_ROWS, vnum), dtype=np.int8)
+
+
+def inspect_lut_dir(exp_dir, scale=4, interval=4):
+    """Describe every ``*_x{scale}_*bit_int8_s{stage}_{mode}.npy`` table in a directory: both the reader-side
+    (``LUT_ft_x4_4bit_...``) and writer-side (``LUT_x4_4bit_...``, sr/2_transfer_to_lut.py:114-116) names, the
+    ``(83521, v_num)`` and ``(83521, 1, u, u)`` shape variants, value range, and the share of rows inside the diagonal
+    band the final-stage kernel keeps in LDS.  Returns a list of dicts (and is what ``python -m mulut_amd.lut_io`` prints)."""
+    import re
+    out = []
+    for fn in sorted(os.listdir(exp_dir)):
+        m = re.match(r"(.+)_x(\d+)_(\d+)bit_int8_s(\d+)_([a-z])\.npy$", fn)
+        if not m:
+            continue
+        arr = np.load(os.path.join(exp_dir, fn))
+        rec = {"file": fn, "lut_name": m.group(1), "scale": int(m.group(2)), "bits": int(m.group(3)),
+               "stage": int(m.group(4)), "mode": m.group(5), "dtype": str(arr.dtype), "shape": tuple(arr.shape)}
+        flat = arr.reshape(arr.shape[0], -1) if arr.ndim >= 2 else arr.reshape(-1, 1)
+        rec["rows_ok"] = flat.shape[0] == L_ROWS
+        rec["v_num"] = int(flat.shape[1])
+        rec["upscale"] = int(round(flat.shape[1] ** 0.5)) if int(round(flat.shape[1] ** 0.5)) ** 2 == flat.shape[1] else None
+        rec["min"], rec["max"] = int(flat.min()), int(flat.max())
+        rec["int8_valued"] = bool(arr.dtype == np.int8 or (np.array_equal(arr, np.round(arr)) and np.abs(arr).max() <= 128))
+        rec["uses_minus128"] = bool(flat.min() == -128)
+        out.append(rec)
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    for r in inspect_lut_dir(sys.argv[1] if len(sys.argv) > 1 else "."):
+        print(json.dumps(r))

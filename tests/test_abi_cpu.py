@@ -97,3 +97,11 @@ def test_metrics_on_reference_outputs():
         ss.append(ssim(y0, y1))
     assert "%.2f" % np.mean(ps) == "30.61"
     assert abs(np.mean(ss) - 0.8655) < 2e-4
+
+
+def test_lut_inspector():
+    recs = lut_io.inspect_lut_dir(os.path.join(GOLDEN, "luts"))
+    assert len(recs) == 6 and all(r["rows_ok"] and r["int8_valued"] for r in recs)
+    by = {(r["stage"], r["mode"]): r for r in recs}
+    assert by[(2, "d")]["v_num"] == 16 and by[(2, "d")]["upscale"] == 4 and by[(2, "d")]["min"] == -120
+    assert by[(1, "s")]["v_num"] == 1 and by[(1, "s")]["lut_name"] == "LUT_ft" and by[(1, "s")]["bits"] == 4
