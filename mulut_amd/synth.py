@@ -24,3 +24,21 @@ def natural_frames(n, h, w, c=3, seed=0):
             acc += rng.normal(0, 2, (h, w)).astype(np.float32)
             out[i, :, :, ch] = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
     return out
+
+
+def real_frames(n, h, w, png_path, seed=0):
+    """D-real: a photograph (the DIV2K LR sample the reference ships) mirrored/tiled to h x w, shifted per frame."""
+    from PIL import Image
+    img = np.array(Image.open(png_path).convert("RGB"))
+    # mirror-tile so that seams are continuous, then crop
+    row = np.concatenate([img, img[:, ::-1]], axis=1)
+    full = np.concatenate([row, row[::-1]], axis=0)
+    reps = (-(-h // full.shape[0]) + 1, -(-w // full.shape[1]) + 1)
+    big = np.tile(full, (reps[0], reps[1], 1))
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, h, w, 3), dtype=np.uint8)
+    for i in range(n):
+        oy = int(rng.integers(0, big.shape[0] - h + 1))
+        ox = int(rng.integers(0, big.shape[1] - w + 1))
+        out[i] = big[oy:oy + h, ox:ox + w]
+    return out

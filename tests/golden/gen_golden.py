@@ -153,6 +153,11 @@ def main():
             shutil.copyfile(os.path.join(REF, src, fn), os.path.join(d, fn))
             os.chmod(os.path.join(d, fn), 0o644)
 
+    # the one DIV2K LR sample the reference ships: real-photo content for bench.py --dist real
+    os.makedirs(os.path.join(HERE, "DIV2K_LR_X4"), exist_ok=True)
+    shutil.copyfile(os.path.join(REF, "data/DIV2K/LR/X4/0001x4.png"), os.path.join(HERE, "DIV2K_LR_X4", "0001x4.png"))
+    os.chmod(os.path.join(HERE, "DIV2K_LR_X4", "0001x4.png"), 0o644)
+
     f32 = {k: v.astype(np.float32) for k, v in shipped.items()}
     luts2 = {k: f32[k].reshape(-1, 16 if k.startswith("s2") else 1) for k in f32}
 

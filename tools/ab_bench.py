@@ -19,7 +19,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mulut_amd import MuLUTEngine, _native, load_lut_dict  # noqa: E402
-from mulut_amd.synth import natural_frames, noise_frames  # noqa: E402
+from mulut_amd.synth import natural_frames, noise_frames, real_frames  # noqa: E402
 
 
 def build_variant(name):
@@ -62,6 +62,9 @@ def main():
         engines[n] = e
     data = {"natural": torch.from_numpy(natural_frames(min(args.frames, 2), args.h, args.w, 3, 0)).cuda(),
             "noise": torch.from_numpy(noise_frames(min(args.frames, 2), args.h, args.w, 3, 0)).cuda()}
+    real_png = os.path.join(ROOT, "tests", "golden", "DIV2K_LR_X4", "0001x4.png")
+    if os.path.exists(real_png):
+        data["real"] = torch.from_numpy(real_frames(min(args.frames, 2), args.h, args.w, real_png, 0)).cuda()
     for k in data:
         data[k] = data[k].repeat((args.frames + 1) // data[k].shape[0], 1, 1, 1)[:args.frames].contiguous()
     out = torch.empty((args.frames, args.h * 4, args.w * 4, 3), dtype=torch.uint8, device="cuda")
