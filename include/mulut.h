@@ -132,8 +132,10 @@ int mulut_ft_stage_backward(int device, const float *const *weights_q, const cha
                             const float *grad_out, int B, int C, int H, int W, float *const *grad_wq, float *grad_x,
                             void *stream);
 
-/* Tuning knobs (never change results).  "final_stage_kernel": 0 = auto, 1 = full-table gather
- * kernel, 2 = compact LDS-band kernel, 3 = expanded LDS-band kernel (2, 3: scale 4, <= 3 modes).  Unknown key or value: MULUT_EINVAL. */
+/* Tuning knobs (never change results).  "final_stage_kernel": 0 = auto (hybrid when scale 4 and <= 3
+ * modes), 1 = full-table gather kernel, 2 = compact LDS-band kernel, 3 = expanded LDS-band kernel, 4 = hybrid (a
+ * per-tile statistic sends smooth 64x16 tiles to the band kernel and detailed ones to the full-table kernel).
+ * "hybrid_oob_per_1024": tile threshold (sites out of band per 1024, default 128).  Unknown key or value: MULUT_EINVAL. */
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value);
 
 /* Name of the kernel variant used for the final / non-final stage (for profiles). */

@@ -34,8 +34,11 @@ struct mulut_ctx {
     size_t ws_bytes = 0;
     std::string hip_err;
     int num_cus = 256;
-    int final_kernel = 0;   // 0 auto (= 3), 1 full-table gather kernel, 2 compact LDS band, 3 expanded LDS band
+    int final_kernel = 0;   // 0 auto (= 4 hybrid), 1 full-table kernel, 2 compact LDS band, 3 expanded LDS band, 4 hybrid
     int f32_ok[2] = {0, 0}; // float epilogue proven exact for the [non-final, final] divisor
+    uint32_t *verdict = nullptr;   // per-tile smooth/detailed verdicts of the hybrid final stage
+    size_t verdict_tiles = 0;
+    int hybrid_oob_per_1024 = 128; // a tile is "detailed" when more than 1/8 of its (sampled) sites leave the band
     bool timing = false;
     hipEvent_t ev[MULUT_MAX_STAGES + 1] = {};
     int timed_stages = 0;
@@ -106,6 +109,7 @@ int mulut_destroy(mulut_ctx *ctx) {
         }
     for (auto &w : ctx->ws)
         if (w) (void)hipFree(w);
+    if (ctx->verdict) (void)hipFree(ctx->verdict);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -257,6 +261,8 @@ static View make_view(const uint8_t *p, int layout, int rows, int W, int C, int 
     return v;
 }
 
+static int ensure_verdict(mulut_ctx *ctx, size_t tiles);
+
 // Launch one stage: input view holds LR rows [in.row0, ...), outputs for LR rows [oy0, oy1).
 static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
                      int C, int oy0, int oy1, hipStream_t st) {
@@ -280,29 +286,51 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.inv_d = 1.0f / (float)a.div.d;
     a.use_f32 = ctx->f32_ok[last ? 1 : 0];
     const bool band = u == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1;
+    const bool hybrid = band && (ctx->final_kernel == 0 || ctx->final_kernel == 4);
+    a.verdict = nullptr;
+    a.verdict_take = -1;
     int tw, th;
     if (u == 1) stage_u1_tile(tw, th); else if (band) stage_band_tile(tw, th); else stage_up_tile(tw, th);
     a.tiles_x = (W + tw - 1) / tw;
     a.tiles_y = (oy1 - oy0 + th - 1) / th;
     if (u == 1) {
         HIP_TRY(ctx, launch_stage_u1(a, st));
-    } else {
-        int mode = kOutGeneric;
-        if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || C == 1)) mode = kOutPlanarU4;
-        else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3) mode = kOutPackedRGBU4;
-        if (band) {
-            const bool x = ctx->final_kernel != 2;   // auto / 3: expanded band; 2: compact band
-            BandArgs b;
-            for (int m = 0; m < ctx->n_modes; ++m) {
-                const DevTable &t = ctx->tab[stage - 1][pattern_id(ctx->modes[m])];
-                b.band[m] = x ? t.bandx : t.band;
-            }
-            if (x) HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
-            else HIP_TRY(ctx, launch_stage_band(a, b, mode, ctx->num_cus, st));
-        } else {
-            HIP_TRY(ctx, launch_stage_up(a, u, mode, st));
-        }
+        return MULUT_OK;
     }
+    int mode = kOutGeneric;
+    if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || C == 1)) mode = kOutPlanarU4;
+    else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3) mode = kOutPackedRGBU4;
+    if (!band) {
+        HIP_TRY(ctx, launch_stage_up(a, u, mode, st));
+        return MULUT_OK;
+    }
+    const bool x = ctx->final_kernel != 2;   // compact band only on request
+    BandArgs b;
+    for (int m = 0; m < ctx->n_modes; ++m) {
+        const DevTable &t = ctx->tab[stage - 1][pattern_id(ctx->modes[m])];
+        b.band[m] = x ? t.bandx : t.band;
+    }
+    if (hybrid) {
+        // per-tile choice on the device: smooth tiles -> LDS band kernel, detailed tiles -> full-table kernel
+        rc = ensure_verdict(ctx, (size_t)N * a.tiles_x * a.tiles_y);
+        if (rc) return rc;
+        HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st));
+        a.verdict = ctx->verdict;
+        a.vt_x = a.tiles_x;
+        a.vt_y = a.tiles_y;
+        a.verdict_take = 0;
+        HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
+        StageArgs g = a;
+        int gw, gh;
+        stage_up_tile(gw, gh);
+        g.tiles_x = (W + gw - 1) / gw;
+        g.tiles_y = (oy1 - oy0 + gh - 1) / gh;
+        g.verdict_take = 1;
+        HIP_TRY(ctx, launch_stage_up(g, u, mode, st));
+        return MULUT_OK;
+    }
+    if (x) HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
+    else HIP_TRY(ctx, launch_stage_band(a, b, mode, ctx->num_cus, st));
     return MULUT_OK;
 }
 
@@ -320,10 +348,26 @@ static int ensure_workspace(mulut_ctx *ctx, size_t bytes) {
     return MULUT_OK;
 }
 
+static int ensure_verdict(mulut_ctx *ctx, size_t tiles) {
+    if (tiles <= ctx->verdict_tiles) return MULUT_OK;
+    if (ctx->verdict) HIP_TRY(ctx, hipFree(ctx->verdict));
+    ctx->verdict = nullptr;
+    ctx->verdict_tiles = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->verdict, tiles * sizeof(uint32_t)));
+    ctx->verdict_tiles = tiles;
+    return MULUT_OK;
+}
+
 int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
     if (!ctx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MULUT_EINVAL;
     if (!ctx->configured) return MULUT_ENOTCONFIGURED;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        int tw, th;
+        stage_band_tile(tw, th);
+        int rc = ensure_verdict(ctx, (size_t)N * ((W + tw - 1) / tw) * ((H + th - 1) / th));
+        if (rc) return rc;
+    }
     if (ctx->stages < 2) return MULUT_OK;
     return ensure_workspace(ctx, (size_t)N * H * W * C);
 }
@@ -414,8 +458,13 @@ int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap) {
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return MULUT_EINVAL;
     if (!strcmp(key, "final_stage_kernel")) {
-        if (value < 0 || value > 3) return MULUT_EINVAL;
+        if (value < 0 || value > 4) return MULUT_EINVAL;
         ctx->final_kernel = value;
+        return MULUT_OK;
+    }
+    if (!strcmp(key, "hybrid_oob_per_1024")) {
+        if (value < 0 || value > 1024) return MULUT_EINVAL;
+        ctx->hybrid_oob_per_1024 = value;
         return MULUT_OK;
     }
     return MULUT_EINVAL;
@@ -425,7 +474,9 @@ const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (!ctx || !ctx->configured) return "";
     if (!is_final || ctx->scale == 1) return stage_u1_name();
     if (ctx->scale == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1)
-        return ctx->final_kernel == 2 ? stage_band_name(kOutPackedRGBU4) : stage_bandx_name(kOutPackedRGBU4);
+        return ctx->final_kernel == 2 ? stage_band_name(kOutPackedRGBU4)
+               : ctx->final_kernel == 3 ? stage_bandx_name(kOutPackedRGBU4)
+                                        : "hybrid: tile_stat_kernel + stage_bandx_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)";
     return stage_up_name(ctx->scale, ctx->scale == 4 ? kOutPackedRGBU4 : kOutGeneric);
 }
 

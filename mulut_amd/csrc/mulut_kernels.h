@@ -40,6 +40,11 @@ struct StageArgs {
     int bias_num;           // numerator bias (127*64*M non-final, 0 final)
     float inv_d;            // fl(1/d) for the float epilogue
     int use_f32;            // float epilogue proven exact for this divisor (rhe_f32_valid)
+    // hybrid final stage: per 64x16-tile verdict written by tile_stat_kernel (0 smooth, 1 detailed).
+    // verdict_take < 0: ignore; otherwise a kernel processes only tiles whose verdict == verdict_take.
+    const uint32_t *verdict;
+    int verdict_take;
+    int vt_x, vt_y;         // verdict grid (64x16 tiles) per image
 };
 
 struct PassArgs {
@@ -69,6 +74,8 @@ hipError_t launch_stage_band(const StageArgs &a, const BandArgs &b, int out_mode
 // same, with the band rows expanded to 16-bit fields in LDS (one mode resident, mode loop outermost)
 hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 const char *stage_bandx_name(int out_mode);
+// per-tile smooth/detailed verdict for the hybrid final stage (tiles of stage_band_tile())
+hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st);
 void stage_band_tile(int &tw, int &th);
 const char *stage_band_name(int out_mode);
 void stage_u1_tile(int &tw, int &th);

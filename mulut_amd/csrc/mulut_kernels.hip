@@ -275,6 +275,62 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Tile statistic for the final stage: how many (pixel, channel) sites of each 64x16 tile have a
+// 5x5 neighbour whose MSB differs from the centre's by more than 1, i.e. at least one of the 12
+// passes of that site leaves the LDS band.  Smooth tiles (few such sites) go to the band kernel,
+// detailed ones to the full-table kernel; both read the per-tile verdict from device memory, so the
+// choice costs no host synchronisation and the pipeline stays capturable into a hipGraph.
+// ------------------------------------------------------------------------------------------
+template <int TW, int TH>
+__global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *verdict, uint32_t max_oob_per_1024) {
+    constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
+    __shared__ uint8_t s_h[3 * PH * PW];
+    __shared__ uint32_t s_cnt, s_valid;
+    int n, y0, x0;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles on one XCD: halo lines fetched once
+    decode_tile(a, id, n, y0, x0, TW, TH);
+    if (threadIdx.x == 0) { s_cnt = 0; s_valid = 0; }
+    const int total = a.C * PH * PW;
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int px = i % PW, py = (i / PW) % PH, c = i / (PW * PH);
+        const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
+        const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
+        s_h[i] = *view_addr(a.in, n, c, gy, gx) >> 4;
+    }
+    __syncthreads();
+    // a verdict is a heuristic: every second site in x and y is enough (4x less LDS work)
+    uint32_t oob = 0, valid = 0;
+    for (int s = threadIdx.x; s < a.C * (TH / 2) * (TW / 2); s += 256) {
+        const int tx = 2 * (s % (TW / 2)), ty = 2 * ((s / (TW / 2)) % (TH / 2)), c = s / ((TW / 2) * (TH / 2));
+        if (y0 + ty >= a.oy1 || x0 + tx >= a.W) continue;
+        const uint8_t *ctr = s_h + c * (PH * PW) + (ty + kHalo) * PW + (tx + kHalo);
+        const int hc = ctr[0];
+        int lo = hc, hi = hc;
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int v = ctr[dy * PW + dx];
+                lo = imin(lo, v);
+                hi = imax(hi, v);
+            }
+        oob += (hi - hc > 1 || hc - lo > 1) ? 1u : 0u;
+        valid += 1u;
+    }
+    for (int o = 32; o > 0; o >>= 1) {   // wave reduction, then one LDS atomic per wave
+        oob += __shfl_down(oob, o);
+        valid += __shfl_down(valid, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_cnt, oob);
+        atomicAdd(&s_valid, valid);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) verdict[id] = (s_cnt * 1024u > max_oob_per_1024 * s_valid) ? 1u : 0u;   // 1 = detailed
+}
+
+// ------------------------------------------------------------------------------------------
 // K2: final stage, u*u-byte rows.
 // One thread = one LR pixel, channels in sequence.  Per rotation the 5*M weighted rows are
 // accumulated as 16-bit fields, two per dword:  lo[k] holds row elements 4k and 4k+2, hi[k] holds
@@ -495,19 +551,46 @@ __device__ __forceinline__ void pass_global(const void *lut, int va, int vb, int
     for (int j = 0; j < 5; ++j) acc.template fma<R>(row[j], (uint32_t)w[j]);
 }
 
-template <int U, int OUT, int TW, int TH>
-__global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
+// HY = false: one block (TW*TH threads) per TW x TH tile.
+// HY = true (hybrid launch): one block of 4*TW*TH threads per 64x16 verdict tile; it exits at once unless the
+// statistic marked the tile for this kernel, otherwise its four thread groups take the four sub-tiles.
+template <int U, int OUT, int TW, int TH, bool HY>
+__global__ void __launch_bounds__(HY ? 4 * TW * TH : TW * TH, 4) stage_up_kernel(StageArgs a) {
     constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
     constexpr int NT = TW * TH;
+    static_assert(!HY || (TW == 32 && TH == 8), "hybrid sub-tiling assumes 2x2 sub-tiles of 32x8 in a 64x16 tile");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *s_img = smem;
 
     int n, y0, x0;
-    decode_tile(a, xcd_remap(blockIdx.x, gridDim.x), n, y0, x0, TW, TH);
-    load_tile<TW, TH, NT>(a, n, y0, x0, s_img);
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int lt = HY ? (threadIdx.x & (NT - 1)) : threadIdx.x;      // thread within its sub-tile group
+    const int sub = HY ? (threadIdx.x / NT) : 0;
+    uint8_t *s_img = smem + sub * (((3 * PH * PW + 15) / 16) * 16);
+    if constexpr (HY) {
+        if ((int)a.verdict[id] != a.verdict_take) return;              // block-uniform
+        int b = id;
+        const int vx = b % a.vt_x;
+        b /= a.vt_x;
+        const int vy = b % a.vt_y;
+        n = b / a.vt_y;
+        y0 = a.oy0 + vy * 16 + (sub >> 1) * TH;
+        x0 = vx * 64 + (sub & 1) * TW;
+    } else {
+        decode_tile(a, id, n, y0, x0, TW, TH);
+    }
+    {   // this group's tile (load_tile, strided by the group's NT threads)
+        const int total = a.C * PH * PW;
+        const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+        for (int i = lt; i < total; i += NT) {
+            const int px = i % PW, py = (i / PW) % PH, c = i / (PW * PH);
+            const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
+            const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
+            s_img[i] = *view_addr(a.in, n, c, gy, gx);
+        }
+    }
     __syncthreads();
 
-    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int tx = lt % TW, ty = lt / TW;
     const int y = y0 + ty, x = x0 + tx;
     if (y >= a.oy1 || x >= a.W) return;
 
@@ -554,10 +637,21 @@ const char *stage_up_name(int u, int out_mode) {
 
 template <int U, int OUT>
 static hipError_t launch_up(const StageArgs &a, hipStream_t st) {
-    const size_t lds = (size_t)a.C * (K2_TH + 2 * kHalo) * (K2_TW + 2 * kHalo);
+    const size_t tile_bytes = ((3 * (size_t)(K2_TH + 2 * kHalo) * (K2_TW + 2 * kHalo) + 15) / 16) * 16;
+    if (a.verdict_take >= 0) {
+        if constexpr (U == 4) {
+            const long long nb = (long long)a.N * a.vt_x * a.vt_y;
+            if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((stage_up_kernel<U, OUT, K2_TW, K2_TH, true>), dim3((unsigned)nb), dim3(4 * K2_TW * K2_TH),
+                               4 * tile_bytes, st, a);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;
     if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((stage_up_kernel<U, OUT, K2_TW, K2_TH>), dim3((unsigned)nb), dim3(K2_TW * K2_TH), lds, st, a);
+    hipLaunchKernelGGL((stage_up_kernel<U, OUT, K2_TW, K2_TH, false>), dim3((unsigned)nb), dim3(K2_TW * K2_TH), tile_bytes, st, a);
     return hipGetLastError();
 }
 
@@ -714,6 +808,13 @@ __global__ void __launch_bounds__(TW *TH) stage_band_kernel(StageArgs a, BandArg
 
 constexpr int KB_TW = 64, KB_TH = 16;
 void stage_band_tile(int &tw, int &th) { tw = KB_TW; th = KB_TH; }
+
+hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st) {
+    const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;   // a.tiles_* must be the 64x16 tiling
+    if (nb <= 0 || nb > 0x7fffffffLL || a.C > 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((tile_stat_kernel<KB_TW, KB_TH>), dim3((unsigned)nb), dim3(256), 0, st, a, verdict, max_oob_per_1024);
+    return hipGetLastError();
+}
 const char *stage_band_name(int out_mode) {
     return out_mode == kOutPackedRGBU4 ? "stage_band_kernel<rgb>" : out_mode == kOutPlanarU4 ? "stage_band_kernel<planar>"
                                                                                                : "stage_band_kernel<generic>";
@@ -874,10 +975,12 @@ __global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandAr
 
     int phase = 0;   // counts (tile, mode) steps of this workgroup: band buffer = phase & 1
     if (first < last) band_dma<NT>((const uint8_t *)b.band[0], s_band);
-    for (int tile = first, it = 0; tile < last; tile += step, ++it) {
+    for (int tile = first, it = 0; tile < last; tile += step) {
+        if (a.verdict_take >= 0 && (int)a.verdict[tile] != a.verdict_take) continue;   // hybrid: not a smooth tile
         int n, y0, x0;
         decode_tile(a, tile, n, y0, x0, TW, TH);
         uint16_t *s_img = (uint16_t *)(s_tile + (it & 1) * kTileBytes);
+        ++it;
         load_tile_code<TW, TH, NT>(a, n, y0, x0, s_img);   // the buffer last read two tiles ago
         const int y = y0 + ty, x = x0 + tx;
         const bool valid = y < a.oy1 && x < a.W;

@@ -56,7 +56,10 @@ def main():
     for n in names:
         e = MuLUTEngine(0, lib_path=libs[n]).configure(2, "sdy", 4, 4).set_lut_dict(luts)
         if "@" in n:
-            e.set_tuning("final_stage_kernel", int(n.split("@")[1]))
+            sel = n.split("@")[1]
+            e.set_tuning("final_stage_kernel", int(sel.split(":")[0]))
+            if ":" in sel:
+                e.set_tuning("hybrid_oob_per_1024", int(sel.split(":")[1]))
         e.reserve(args.frames, args.h, args.w, 3)
         e.set_stage_timing(True)
         engines[n] = e
