@@ -551,21 +551,21 @@ __device__ __forceinline__ void pass_global(const void *lut, int va, int vb, int
     for (int j = 0; j < 5; ++j) acc.template fma<R>(row[j], (uint32_t)w[j]);
 }
 
-// HY = false: one block (TW*TH threads) per TW x TH tile.
-// HY = true (hybrid launch): one block of 4*TW*TH threads per 64x16 verdict tile; it exits at once unless the
-// statistic marked the tile for this kernel, otherwise its four thread groups take the four sub-tiles.
+// HY = false: one block per TW x TH tile.
+// HY = true (hybrid launch): four blocks per 64x16 verdict tile (its 2x2 sub-tiles); a block exits at once
+// unless the statistic marked the tile for this kernel (an empty block costs ~0.3 us of one CU).
 template <int U, int OUT, int TW, int TH, bool HY>
-__global__ void __launch_bounds__(HY ? 4 * TW * TH : TW * TH, 4) stage_up_kernel(StageArgs a) {
+__global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
     constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
     constexpr int NT = TW * TH;
     static_assert(!HY || (TW == 32 && TH == 8), "hybrid sub-tiling assumes 2x2 sub-tiles of 32x8 in a 64x16 tile");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     int n, y0, x0;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int lt = HY ? (threadIdx.x & (NT - 1)) : threadIdx.x;      // thread within its sub-tile group
-    const int sub = HY ? (threadIdx.x / NT) : 0;
-    uint8_t *s_img = smem + sub * (((3 * PH * PW + 15) / 16) * 16);
+    const int id = HY ? xcd_remap(blockIdx.x >> 2, gridDim.x >> 2) : xcd_remap(blockIdx.x, gridDim.x);
+    const int lt = threadIdx.x;
+    const int sub = HY ? (blockIdx.x & 3) : 0;
+    uint8_t *s_img = smem;
     if constexpr (HY) {
         if ((int)a.verdict[id] != a.verdict_take) return;              // block-uniform
         int b = id;
@@ -640,10 +640,10 @@ static hipError_t launch_up(const StageArgs &a, hipStream_t st) {
     const size_t tile_bytes = ((3 * (size_t)(K2_TH + 2 * kHalo) * (K2_TW + 2 * kHalo) + 15) / 16) * 16;
     if (a.verdict_take >= 0) {
         if constexpr (U == 4) {
-            const long long nb = (long long)a.N * a.vt_x * a.vt_y;
+            const long long nb = 4LL * a.N * a.vt_x * a.vt_y;
             if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((stage_up_kernel<U, OUT, K2_TW, K2_TH, true>), dim3((unsigned)nb), dim3(4 * K2_TW * K2_TH),
-                               4 * tile_bytes, st, a);
+            hipLaunchKernelGGL((stage_up_kernel<U, OUT, K2_TW, K2_TH, true>), dim3((unsigned)nb), dim3(K2_TW * K2_TH),
+                               tile_bytes, st, a);
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;
