@@ -26,8 +26,9 @@ def main(path, workload, out):
         if "read_bytes" in e and "write_bytes" in e:
             e["hbm_bytes"] = e["read_bytes"] + e["write_bytes"]
         rec["kernels"][k] = e
-        if "stage_band" in k or "stage_up" in k:
-            rec["final_stage_bytes_per_launch"] = e.get("hbm_bytes")
+        if ("stage_band" in k or "stage_up" in k or "tile_stat" in k) and e.get("hbm_bytes") is not None:
+            # the final stage may be several kernels (hybrid: statistic + band kernel + full-table kernel)
+            rec["final_stage_bytes_per_launch"] = rec.get("final_stage_bytes_per_launch", 0.0) + e["hbm_bytes"]
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec, indent=1))
 
