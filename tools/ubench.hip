@@ -82,6 +82,29 @@ __global__ void __launch_bounds__(1024) lds_gather(uint32_t *out, int iters, uin
 
 // global gather of 16-B rows from a table of `rows` rows; locality: lanes of a wave draw their row
 // from a window of `window` rows around a per-wave random centre
+// same gather with only `active_of_8` of every 8 lanes issuing the load (exec-masked): does TA cost scale with lanes?
+__global__ void __launch_bounds__(256) glb_gather_masked(const uint4 *tab, uint32_t *out, int iters, uint32_t rows,
+                                                         uint32_t window, uint32_t active_of_8) {
+    uint32_t lane_s = (blockIdx.x * blockDim.x + threadIdx.x) * 747796405u + 99u;
+    uint32_t wave_s = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 2891336453u + 99u;
+    uint32_t acc = 0;
+    const bool on = (threadIdx.x & 7) < active_of_8;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            lane_s = lane_s * 1664525u + 1013904223u;
+            wave_s = wave_s * 22695477u + 1u;
+            uint32_t centre = (wave_s >> 4) & (rows - 1);               // rows and window are powers of two:
+            uint32_t idx = (centre + ((lane_s >> 10) & (window - 1))) & (rows - 1);   // no integer division in the loop
+            if (on) {
+                uint4 v = tab[idx];
+                acc += v.x ^ v.y ^ v.z ^ v.w;
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 __global__ void __launch_bounds__(256) glb_gather(const uint4 *tab, uint32_t *out, int iters, uint32_t rows,
                                                   uint32_t window, uint32_t seed) {
     uint32_t lane_s = (blockIdx.x * blockDim.x + threadIdx.x) * 747796405u + seed;
@@ -92,8 +115,8 @@ __global__ void __launch_bounds__(256) glb_gather(const uint4 *tab, uint32_t *ou
         for (int u = 0; u < 8; ++u) {
             lane_s = lane_s * 1664525u + 1013904223u;
             wave_s = wave_s * 22695477u + 1u;
-            uint32_t centre = (wave_s >> 4) % rows;
-            uint32_t idx = (centre + ((lane_s >> 10) % window)) % rows;
+            uint32_t centre = (wave_s >> 4) & (rows - 1);
+            uint32_t idx = (centre + ((lane_s >> 10) & (window - 1))) & (rows - 1);
             uint4 v = tab[idx];
             acc += v.x ^ v.y ^ v.z ^ v.w;
         }
@@ -133,6 +156,10 @@ static void launch_lds(void *c) {
     Ctx *x = (Ctx *)c;
     hipLaunchKernelGGL(lds_gather<W>, dim3(256), dim3(1024), 80 * 1024, 0, x->out, x->iters, x->p0, 777u);
 }
+static void launch_glb_masked(void *c) {
+    Ctx *x = (Ctx *)c;
+    hipLaunchKernelGGL(glb_gather_masked, dim3(256 * 8), dim3(256), 0, 0, x->tab, x->out, x->iters, x->p0, x->p1, (uint32_t)x->op);
+}
 static void launch_glb(void *c) {
     Ctx *x = (Ctx *)c;
     hipLaunchKernelGGL(glb_gather, dim3(256 * 8), dim3(256), 0, 0, x->tab, x->out, x->iters, x->p0, x->p1, 99u);
@@ -146,7 +173,7 @@ int main() {
            prop.multiProcessorCount, ghz);
     Ctx c;
     CK(hipMalloc(&c.out, 256 * 8 * 1024 * 4));
-    const uint32_t rows = 83521;
+    const uint32_t rows = 65536;   // power of two (1 MiB of 16-byte rows), close to the 83521-row tables
     std::vector<uint32_t> h(rows * 4);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (uint32_t)i * 2654435761u;
     uint4 *tab;
@@ -186,7 +213,7 @@ int main() {
     }
     // ---- global 16-B row gathers from a 1.3 MB table ----
     c.iters = 100;
-    uint32_t wins[] = {1, 4, 16, 64, 256, 1024, 4096, 83521};
+    uint32_t wins[] = {1, 4, 16, 64, 256, 1024, 4096, 65536};
     for (uint32_t w : wins) {
         c.p0 = rows;
         c.p1 = w;
@@ -195,5 +222,13 @@ int main() {
         printf("GLB  dwordx4 gather, lanes within %5u rows of a per-wave centre: %8.3f ms -> %.1f cycles per wave-instruction per CU\n",
                w, ms, ms * 1e-3 * ghz * 1e9 / winst_per_cu);
     }
+    for (uint32_t w : {64u, 4096u})
+        for (int act : {8, 4, 2, 1}) {
+            c.p0 = rows; c.p1 = w; c.op = act;
+            float ms = time_ms(launch_glb_masked, &c, 5);
+            const double winst_per_cu = (256.0 * 8 * 4 / prop.multiProcessorCount) * c.iters * 8;
+            printf("GLB  dwordx4 gather, %d of 8 lanes active, window %5u rows: %8.3f ms -> %.1f cycles per wave-instruction per CU\n",
+                   act, w, ms, ms * 1e-3 * ghz * 1e9 / winst_per_cu);
+        }
     return 0;
 }
