@@ -324,3 +324,36 @@ def test_pipeline_replays_from_a_captured_graph():
                                                 for im in np.roll(img, trial, axis=2)])
         assert np.array_equal(out.cpu().numpy(), ref), trial
     e.close()
+
+
+def test_hybrid_final_stage_variants_agree_and_capture(eng, shipped_luts):
+    """Every final-stage variant (full-table, compact band, expanded band, hybrid with several thresholds) gives
+    the same bytes on smooth, photographic and noisy content; the default (hybrid) path replays from a hipGraph."""
+    from mulut_amd.synth import natural_frames, noise_frames, real_frames
+    png = os.path.join(GOLDEN, "DIV2K_LR_X4", "0001x4.png")
+    frames = np.concatenate([natural_frames(1, 150, 200, 3, 1), noise_frames(1, 150, 200, 3, 1),
+                             real_frames(1, 150, 200, png, 1)])
+    x = dev(frames)
+    eng.set_tuning("final_stage_kernel", 1)
+    want = eng.pipeline(x).clone()
+    assert np.array_equal(want[2].cpu().numpy(), c_oracle.pipeline(shipped_luts, 2, "sdy", 4, frames[2]))
+    for sel, thr in ((2, None), (3, None), (4, 0), (4, 128), (4, 1024), (0, None)):
+        eng.set_tuning("final_stage_kernel", sel)
+        if thr is not None:
+            eng.set_tuning("hybrid_oob_per_1024", thr)
+        assert torch.equal(eng.pipeline(x), want), (sel, thr)
+    eng.set_tuning("hybrid_oob_per_1024", 128).set_tuning("final_stage_kernel", 0)
+    # capture the default path
+    out = torch.empty_like(want)
+    eng.reserve(3, 150, 200, 3)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng.pipeline(x, out=out)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.pipeline(x, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
