@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Bit-compare every final-stage kernel variant against the full-table kernel on smooth / photo / noise frames."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mulut_amd import MuLUTEngine, load_lut_dict
+from mulut_amd.synth import natural_frames, noise_frames, real_frames
+
+luts = load_lut_dict(os.path.join(ROOT, "tests", "golden", "luts"), 2, "sdy", 4, 4, "LUT_ft")
+e = MuLUTEngine(0).configure(2, "sdy", 4, 4).set_lut_dict(luts)
+png = os.path.join(ROOT, "tests", "golden", "DIV2K_LR_X4", "0001x4.png")
+ok = True
+for (h, w) in ((150, 200), (37, 129), (270, 480)):
+    fr = np.concatenate([natural_frames(1, h, w, 3, 1), noise_frames(1, h, w, 3, 1), real_frames(1, h, w, png, 1)])
+    x = torch.from_numpy(fr).cuda()
+    e.set_tuning("final_stage_kernel", 1)
+    want = e.pipeline(x).clone()
+    for sel in (3, 4):
+        for v in (0, 1):
+            e.set_tuning("final_stage_kernel", sel).set_tuning("bandx_variant", v)
+            got = e.pipeline(x)
+            same = torch.equal(got, want)
+            ok &= same
+            print(h, w, "kernel", sel, "variant", v, "OK" if same else "MISMATCH %d" % int((got != want).sum()))
+sys.exit(0 if ok else 1)
