@@ -38,7 +38,6 @@ struct mulut_ctx {
     int f32_ok[2] = {0, 0}; // float epilogue proven exact for the [non-final, final] divisor
     uint32_t *verdict = nullptr;   // per-tile smooth/detailed verdicts of the hybrid final stage
     size_t verdict_tiles = 0;
-    int bandx_variant = 1;         // 0: mode-phase kernel (stage_bandx_kernel), 1: rotation-pair-phase kernel (stage_bandy_kernel)
     int hybrid_oob_per_1024 = 128; // a tile is "detailed" when more than 1/8 of its (sampled) sites leave the band
     bool timing = false;
     hipEvent_t ev[MULUT_MAX_STAGES + 1] = {};
@@ -320,7 +319,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.vt_x = a.tiles_x;
         a.vt_y = a.tiles_y;
         a.verdict_take = 0;
-        HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st, ctx->bandx_variant));
+        HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
         StageArgs g = a;
         int gw, gh;
         stage_up_tile(gw, gh);
@@ -330,7 +329,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         HIP_TRY(ctx, launch_stage_up(g, u, mode, st));
         return MULUT_OK;
     }
-    if (x) HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st, ctx->bandx_variant));
+    if (x) HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
     else HIP_TRY(ctx, launch_stage_band(a, b, mode, ctx->num_cus, st));
     return MULUT_OK;
 }
@@ -461,11 +460,6 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "final_stage_kernel")) {
         if (value < 0 || value > 4) return MULUT_EINVAL;
         ctx->final_kernel = value;
-        return MULUT_OK;
-    }
-    if (!strcmp(key, "bandx_variant")) {
-        if (value < 0 || value > 1) return MULUT_EINVAL;
-        ctx->bandx_variant = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "hybrid_oob_per_1024")) {

@@ -72,7 +72,7 @@ hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t 
 // final stage, u == 4, M <= 3: band tables resident in LDS, persistent workgroups
 hipError_t launch_stage_band(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 // same, with the band rows expanded to 16-bit fields in LDS (one mode resident, mode loop outermost)
-hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st, int variant);
+hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 const char *stage_bandx_name(int out_mode);
 // per-tile smooth/detailed verdict for the hybrid final stage (tiles of stage_band_tile())
 hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st);

@@ -872,25 +872,6 @@ __device__ __forceinline__ void band_dma(const uint8_t *gsrc, uint8_t *lds_dst) 
     }
 }
 
-// The same copy issued from inline asm: the compiler's wait-count pass does not see it, so it does not put
-// an s_waitcnt vmcnt(0) (it cannot prove the two band buffers distinct) in front of the next LDS read; the
-// kernel waits explicitly before the barrier that publishes the buffer.  Untracked outstanding operations
-// only ever make the compiler's own vmcnt waits more conservative (the counter retires in order).
-template <int NT>
-__device__ __forceinline__ void band_dma_untracked(const uint8_t *gsrc, uint8_t *lds_dst) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds_dst;
-    for (int piece = wave; piece < kBandXBytes / 1024; piece += NT / 64) {
-        const uint8_t *g = gsrc + piece * 1024 + lane * 16;
-        const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)piece * 1024u);
-        uint32_t keep;   // M0 is restored: the compiler does not expect inline asm to change it
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "s"(m0v), "v"(g)
-                     : "memory");
-    }
-}
-
 template <int R, int HALF>
 __device__ __forceinline__ void rows_x(const uint8_t *band, const BandPair &bp, RotAcc<4> &acc) {
     // depth-1 software pipeline over the five rows: row j+1 is in flight while row j is accumulated
@@ -945,9 +926,20 @@ __device__ __forceinline__ void pass_global_lean(const void *lut, int va, int vb
     }
 }
 
+#if defined(MULUT_PROFILE)
+struct WaveProf {
+    unsigned long long t_slow, n_slow, t_fast, n_fast;
+};
+__device__ WaveProf *g_prof_dummy;
+#define PROF_ARG , WaveProf &prof
+#define PROF_PASS , prof
+#else
+#define PROF_ARG
+#define PROF_PASS
+#endif
 template <int R>
 __device__ __forceinline__ void pair_x(const uint8_t *band, const void *lut, const uint16_t *ctr, int o0, int o1, int o2,
-                                       RotAcc<4> &acc) {
+                                       RotAcc<4> &acc PROF_ARG) {
     // the tile holds pixel codes: a key is one v_and_or of a packed pair, the 16*h term one v_and
     const uint32_t ca = ctr[0];
 #if MULUT_ABLATE == 8   /* timing-only: no neighbour reads, index math hoistable */
@@ -962,6 +954,17 @@ __device__ __forceinline__ void pair_x(const uint8_t *band, const void *lut, con
 #endif
     BandPair bp;
     simplex4_band_pair_code(ca, pb, pc, pd, bp);
+#if defined(MULUT_PROFILE)
+    const unsigned long long pq0 = __builtin_amdgcn_s_memtime();
+    const bool pq_fast = __all(bp.t_band == 0u);
+    struct PQ {
+        WaveProf &p; unsigned long long t0; bool fast;
+        __device__ ~PQ() {
+            const unsigned long long d = __builtin_amdgcn_s_memtime() - t0;
+            if (fast) { p.t_fast += d; p.n_fast += 1; } else { p.t_slow += d; p.n_slow += 1; }
+        }
+    } pq{prof, pq0, pq_fast};
+#endif
     if (__all(bp.t_band == 0u)) {          // both passes in band in every lane
         rows_x<R, 0>(band, bp, acc);
         rows_x<R + 2, 1>(band, bp, acc);
@@ -993,6 +996,11 @@ __global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandAr
     const int last = by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, ntiles) : ntiles;
     const int step = by_xcd ? (G >> 3) : G;
 
+#if defined(MULUT_PROFILE)
+    WaveProf prof = {0, 0, 0, 0};
+    unsigned long long pt_bar = 0, pt_epi = 0, pt_load = 0;
+    const unsigned long long pt_begin = __builtin_amdgcn_s_memtime();
+#endif
     int phase = 0;   // counts (tile, mode) steps of this workgroup: band buffer = phase & 1
     if (first < last) band_dma<NT>((const uint8_t *)b.band[0], s_band);
     for (int tile = first, it = 0; tile < last; tile += step) {
@@ -1001,7 +1009,13 @@ __global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandAr
         decode_tile(a, tile, n, y0, x0, TW, TH);
         uint16_t *s_img = (uint16_t *)(s_tile + (it & 1) * kTileBytes);
         ++it;
+#if defined(MULUT_PROFILE)
+        const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
         load_tile_code<TW, TH, NT>(a, n, y0, x0, s_img);   // the buffer last read two tiles ago
+#if defined(MULUT_PROFILE)
+        pt_load += __builtin_amdgcn_s_memtime() - pt0;
+#endif
         const int y = y0 + ty, x = x0 + tx;
         const bool valid = y < a.oy1 && x < a.W;
         const uint16_t *ctr = s_img + (ty + kHalo) * PW + (tx + kHalo);
@@ -1011,8 +1025,14 @@ __global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandAr
             const int m = __builtin_amdgcn_readfirstlane(mv);
             // my DMA pieces of this phase's band have landed; after the barrier everyone's have, the image
             // tile is visible, and every wave has finished the previous phase (its band buffer is free)
+#if defined(MULUT_PROFILE)
+            const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+#if defined(MULUT_PROFILE)
+            pt_bar += __builtin_amdgcn_s_memtime() - pt1;
+#endif
             const uint8_t *band = s_band + (phase & 1) * kBandXBytes;
             {   // prefetch the next phase's band (next mode, or mode 0 of the next tile) into the other buffer
                 const int mnext = mv + 1 < a.M ? mv + 1 : 0;
@@ -1035,354 +1055,17 @@ __global__ void __launch_bounds__(TW *TH) stage_bandx_kernel(StageArgs a, BandAr
                 sample_offset(1, a.di[m][0], a.dj[m][0], dy, dx); const int q0 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
                 sample_offset(1, a.di[m][1], a.dj[m][1], dy, dx); const int q1 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
                 sample_offset(1, a.di[m][2], a.dj[m][2], dy, dx); const int q2 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
-                pair_x<0>(band, lut, ctr, p0, p1, p2, acc0);
-                pair_x<1>(band, lut, ctr, q0, q1, q2, acc0);
+                pair_x<0>(band, lut, ctr, p0, p1, p2, acc0 PROF_PASS);
+                pair_x<1>(band, lut, ctr, q0, q1, q2, acc0 PROF_PASS);
                 if (a.C > 1) {
-                    pair_x<0>(band, lut, ctr + PH * PW, p0, p1, p2, acc1);
-                    pair_x<1>(band, lut, ctr + PH * PW, q0, q1, q2, acc1);
+                    pair_x<0>(band, lut, ctr + PH * PW, p0, p1, p2, acc1 PROF_PASS);
+                    pair_x<1>(band, lut, ctr + PH * PW, q0, q1, q2, acc1 PROF_PASS);
                 }
                 if (a.C > 2) {
-                    pair_x<0>(band, lut, ctr + 2 * PH * PW, p0, p1, p2, acc2);
-                    pair_x<1>(band, lut, ctr + 2 * PH * PW, q0, q1, q2, acc2);
+                    pair_x<0>(band, lut, ctr + 2 * PH * PW, p0, p1, p2, acc2 PROF_PASS);
+                    pair_x<1>(band, lut, ctr + 2 * PH * PW, q0, q1, q2, acc2 PROF_PASS);
                 }
             }
-        }
-        if (valid) {
-            if constexpr (OUT == kOutPackedRGBU4) {
-                finish_store_rgb4(a, acc0, acc1, acc2, n, y, x);
-            } else {
-                uint32_t o[U];
-                finish_channel<U, OUT>(a, acc0, n, 0, y, x, o);
-                if (a.C > 1) finish_channel<U, OUT>(a, acc1, n, 1, y, x, o);
-                if (a.C > 2) finish_channel<U, OUT>(a, acc2, n, 2, y, x, o);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K2-band-y: the expanded-band kernel run in rotation-pair PHASES.  A tile is processed as
-//      (mode 0, rot 1+3) (mode 1, rot 1+3) .. (mode M-1, rot 1+3) | (mode M-1, rot 0+2) .. (mode 0, rot 0+2)
-// Rotations 1 and 3 accumulate in rotation-1 element order; between the two halves the 8 accumulator
-// dwords of a channel are transposed in registers to block order (= rotation-0 order), in which
-// rotations 0 and 2 then accumulate.  A pixel therefore carries 3 x 8 accumulator VGPRs instead of
-// 3 x 16, and the registers saved hold a second row pair in flight: the rows of both rotations of a
-// pair are fetched together (4 ds_read_b128 ahead of 16 v_pk_mad_u16).  The mode order makes two
-// of the 2M phases reuse the band already resident (the turn-around, and the next tile's first
-// phase), so a tile costs 2M-2 (+1) band transfers.
-// ------------------------------------------------------------------------------------------
-#ifndef MULUT_Y6_AHEAD
-#define MULUT_Y6_AHEAD 2
-#endif
-struct PairAcc {
-    uint32_t lo[4], hi[4];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lo[k] = hi[k] = 0;
-    }
-    // REV = 0: first rotation of the pair (r), REV = 1: second (r+2, reversed element order)
-    template <int REV, int HALF>
-    __device__ __forceinline__ void fma_x(const uint32_t (&rlo)[4], const uint32_t (&rhi)[4], uint32_t wpk) {
-        if constexpr (REV == 0) swar_fma_x4<HALF>(lo, hi, rlo, rhi, wpk);
-        else swar_fma_x4_rev<HALF>(lo, hi, rlo, rhi, wpk);
-    }
-    template <int REV>
-    __device__ __forceinline__ void fma(const uint32_t (&row)[4], uint32_t w) {
-        if constexpr (REV == 0) swar_fma<4>(lo, hi, row, w);
-        else swar_fma_rev4(lo, hi, row, w);
-    }
-    // rotation-1 element order -> block order (combine_pairs4 with an empty (0,2) accumulator)
-    __device__ __forceinline__ void to_block_order() {
-        const uint32_t z[4] = {0u, 0u, 0u, 0u};
-        uint32_t l[4], h[4];
-        combine_pairs4(z, z, lo, hi, l, h);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { lo[k] = l[k]; hi[k] = h[k]; }
-    }
-    __device__ __forceinline__ void finalize() {}
-    template <int SY, int SX>
-    __device__ __forceinline__ uint32_t sum() const {
-        const uint32_t word = (SX & 1) ? hi[SY] : lo[SY];
-        return (SX & 2) ? (word >> 16) : (word & 0xFFFFu);
-    }
-};
-
-// the five rows of BOTH passes of a pair, one row pair ahead
-__device__ __forceinline__ void rows_y2(const uint8_t *band, const BandPair &bp, PairAcc &acc) {
-    uint4 a0, a1, b0, b1, na0, na1, nb0, nb1;
-    auto ld = [&](int j, uint4 &x0, uint4 &x1, uint4 &y0, uint4 &y1) {
-        const uint32_t oa = bp.addr[j] & 0xFFFFu, ob = bp.addr[j] >> 16;
-        x0 = *(const uint4 *)(band + oa);
-        x1 = *(const uint4 *)(band + oa + kPlaneBytes);
-        y0 = *(const uint4 *)(band + ob);
-        y1 = *(const uint4 *)(band + ob + kPlaneBytes);
-    };
-    ld(0, a0, a1, b0, b1);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        if (j < 4) ld(j + 1, na0, na1, nb0, nb1);
-        {
-            const uint32_t rlo[4] = {a0.x, a0.y, a0.z, a0.w}, rhi[4] = {a1.x, a1.y, a1.z, a1.w};
-            acc.template fma_x<0, 0>(rlo, rhi, bp.w[j]);
-        }
-        {
-            const uint32_t rlo[4] = {b0.x, b0.y, b0.z, b0.w}, rhi[4] = {b1.x, b1.y, b1.z, b1.w};
-            acc.template fma_x<1, 1>(rlo, rhi, bp.w[j]);
-        }
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-    }
-}
-
-// one pass of a pair (HALF = which), depth-1 pipeline
-template <int HALF>
-__device__ __forceinline__ void rows_y1(const uint8_t *band, const BandPair &bp, PairAcc &acc) {
-    uint4 c0, c1, n0, n1;
-    auto ld = [&](int j, uint4 &v0, uint4 &v1) {
-        const uint32_t off = HALF ? (bp.addr[j] >> 16) : (bp.addr[j] & 0xFFFFu);
-        v0 = *(const uint4 *)(band + off);
-        v1 = *(const uint4 *)(band + off + kPlaneBytes);
-    };
-    ld(0, c0, c1);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        if (j < 4) ld(j + 1, n0, n1);
-        const uint32_t rlo[4] = {c0.x, c0.y, c0.z, c0.w}, rhi[4] = {c1.x, c1.y, c1.z, c1.w};
-        acc.template fma_x<HALF, HALF>(rlo, rhi, bp.w[j]);
-        c0 = n0;
-        c1 = n1;
-    }
-}
-
-// out-of-band pass against the full table: the five row gathers are issued together, the caller does its
-// LDS work, and only then are the rows accumulated -- one L2 round trip per pair instead of five per pass
-// (a workgroup advances at the pace of its slowest wave, so this latency is on the critical path of a phase)
-struct GlobalRows {
-    uint32_t r[5][4];
-    int w[5];
-};
-__device__ __forceinline__ void global_rows_issue(const void *lut, int va, int vb, int vc, int vd, GlobalRows &g) {
-    int idx[5];
-    simplex4(va, vb, vc, vd, idx, g.w);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) load_row<4>(lut, idx[j], g.r[j]);
-}
-template <int REV>
-__device__ __forceinline__ void global_rows_mac(const GlobalRows &g, PairAcc &acc) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) acc.template fma<REV>(g.r[j], (uint32_t)g.w[j]);
-}
-
-// both rotations (r: low halves, r+2: high halves) of one channel of one pixel against one mode -- the general
-// form (some lane of the wave is out of band).  A real (not inlined) function that returns the pair's
-// contribution by value: the rare path gets its own register allocation instead of shaping the whole kernel's.
-struct PairDelta {
-    uint32_t lo[4], hi[4];
-};
-__device__ __attribute__((noinline)) PairDelta pair_general(uint32_t band_lds, const void *lut, uint32_t ctr_lds, int o0, int o1, int o2) {
-    const uint8_t *band = (const uint8_t *)(__attribute__((address_space(3))) const uint8_t *)(uintptr_t)band_lds;
-    const uint16_t *ctr = (const uint16_t *)(__attribute__((address_space(3))) const uint16_t *)(uintptr_t)ctr_lds;
-    const uint32_t ca = ctr[0];
-    const uint32_t pb = ctr[o0] | ((uint32_t)ctr[-o0] << 16);
-    const uint32_t pc = ctr[o1] | ((uint32_t)ctr[-o1] << 16);
-    const uint32_t pd = ctr[o2] | ((uint32_t)ctr[-o2] << 16);
-    BandPair bp;
-    simplex4_band_pair_code(ca, pb, pc, pd, bp);
-    PairAcc acc;
-    acc.clear();
-    if (__all(bp.t_band == 0u)) {
-        rows_y2(band, bp, acc);
-    } else {
-        const int va = pixel_value(ca);
-        const bool out0 = (bp.t_band & 0xFFFFu) != 0u, out1 = (bp.t_band >> 16) != 0u;
-        GlobalRows g0, g1;
-        if (out0) global_rows_issue(lut, va, pixel_value(pb & 0xFFFFu), pixel_value(pc & 0xFFFFu), pixel_value(pd & 0xFFFFu), g0);
-        if (out1) global_rows_issue(lut, va, pixel_value(pb >> 16), pixel_value(pc >> 16), pixel_value(pd >> 16), g1);
-        if (!out0) rows_y1<0>(band, bp, acc);
-        if (!out1) rows_y1<1>(band, bp, acc);
-        if (out0) global_rows_mac<0>(g0, acc);
-        if (out1) global_rows_mac<1>(g1, acc);
-    }
-    PairDelta d;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { d.lo[k] = acc.lo[k]; d.hi[k] = acc.hi[k]; }
-    return d;
-}
-__device__ __forceinline__ void pair_y(const uint8_t *band, const void *lut, const uint16_t *ctr, int o0, int o1, int o2,
-                                       PairAcc &acc) {
-    const uint32_t band_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)band;
-    const uint32_t ctr_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint16_t *)ctr;
-    const PairDelta d = pair_general(band_lds, lut, ctr_lds, o0, o1, o2);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { acc.lo[k] = pk_add(acc.lo[k], d.lo[k]); acc.hi[k] = pk_add(acc.hi[k], d.hi[k]); }
-}
-
-// The all-in-band phase body of an RGB pixel: the 3 x 5 row steps of the three channel pairs as ONE software
-// pipeline, AHEAD row steps (4 ds_read_b128 each) in flight in front of the 16 v_pk_mad_u16 of the current
-// one, with no gap at the pair boundaries (all three index computations are done before the first row).
-struct RowQuad {
-    uint4 a0, a1, b0, b1;
-};
-template <int AHEAD>
-__device__ __forceinline__ void rows_y6(const uint8_t *band, const BandPair &bp0, const BandPair &bp1, const BandPair &bp2,
-                                        PairAcc &acc0, PairAcc &acc1, PairAcc &acc2) {
-    RowQuad buf[AHEAD + 1];
-    auto ld = [&](auto S) {
-        constexpr int s = S, p = s / 5, j = s % 5;
-        const BandPair &bp = p == 0 ? bp0 : p == 1 ? bp1 : bp2;
-        RowQuad &q = buf[s % (AHEAD + 1)];
-        const uint32_t oa = bp.addr[j] & 0xFFFFu, ob = bp.addr[j] >> 16;
-        q.a0 = *(const uint4 *)(band + oa);
-        q.a1 = *(const uint4 *)(band + oa + kPlaneBytes);
-        q.b0 = *(const uint4 *)(band + ob);
-        q.b1 = *(const uint4 *)(band + ob + kPlaneBytes);
-    };
-    static_for<0, AHEAD>([&](auto S) { ld(S); });
-    static_for<0, 15>([&](auto S) {
-        constexpr int s = S, p = s / 5, j = s % 5;
-        if constexpr (s + AHEAD < 15) ld(IC<s + AHEAD>{});
-        const BandPair &bp = p == 0 ? bp0 : p == 1 ? bp1 : bp2;
-        PairAcc &acc = p == 0 ? acc0 : p == 1 ? acc1 : acc2;
-        const RowQuad &q = buf[s % (AHEAD + 1)];
-        {
-            const uint32_t rlo[4] = {q.a0.x, q.a0.y, q.a0.z, q.a0.w}, rhi[4] = {q.a1.x, q.a1.y, q.a1.z, q.a1.w};
-            acc.template fma_x<0, 0>(rlo, rhi, bp.w[j]);
-        }
-        {
-            const uint32_t rlo[4] = {q.b0.x, q.b0.y, q.b0.z, q.b0.w}, rhi[4] = {q.b1.x, q.b1.y, q.b1.z, q.b1.w};
-            acc.template fma_x<1, 1>(rlo, rhi, bp.w[j]);
-        }
-#if defined(MULUT_SCHED_BARRIER)
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    });
-}
-
-template <int OUT, int TW, int TH>
-__global__ void __launch_bounds__(TW *TH) stage_bandy_kernel(StageArgs a, BandArgs b) {
-    constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
-    constexpr int NT = TW * TH;
-    constexpr int U = 4;
-    constexpr int kTileBytes = ((2 * 3 * PH * PW + 15) / 16) * 16;   // 16-bit pixel codes
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *s_band = smem;                       // two buffers of kBandXBytes
-    uint8_t *s_tile = smem + 2 * kBandXBytes;     // two buffers of kTileBytes
-
-    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
-    const int ntiles = a.N * a.tiles_x * a.tiles_y;
-    const int G = gridDim.x;
-    const bool by_xcd = (G & 7) == 0;
-    const int per = (ntiles + 7) >> 3;
-    const int first = by_xcd ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int last = by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, ntiles) : ntiles;
-    const int step = by_xcd ? (G >> 3) : G;
-    const int M = a.M, P = 2 * a.M;
-    auto mode_of = [&](int q) { return q < M ? q : P - 1 - q; };   // phase -> mode
-
-#if defined(MULUT_PROFILE)   /* per-wave time split, written behind the last output frame (tools/prof_phases.py) */
-    unsigned long long pt_load = 0, pt_bar = 0, pt_cmp = 0, pt_epi = 0, pt_slow = 0;
-    const unsigned long long pt_begin = __builtin_amdgcn_s_memtime();
-#endif
-    int cur = 0;                 // band buffer the current phase reads
-    int held0 = 0, held1 = -1;   // mode whose band a buffer holds (or is being filled with)
-    if (first < last) band_dma_untracked<NT>((const uint8_t *)b.band[0], s_band);
-    for (int tile = first, it = 0; tile < last; tile += step) {
-        if (a.verdict_take >= 0 && (int)a.verdict[tile] != a.verdict_take) continue;   // hybrid: not a smooth tile
-        int n, y0, x0;
-        decode_tile(a, tile, n, y0, x0, TW, TH);
-        uint16_t *s_img = (uint16_t *)(s_tile + (it & 1) * kTileBytes);
-        ++it;
-#if defined(MULUT_PROFILE)
-        const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
-#endif
-        load_tile_code<TW, TH, NT>(a, n, y0, x0, s_img);   // the buffer last read two tiles ago
-#if defined(MULUT_PROFILE)
-        pt_load += __builtin_amdgcn_s_memtime() - pt0;
-#endif
-        const int y = y0 + ty, x = x0 + tx;
-        const bool valid = y < a.oy1 && x < a.W;
-        const bool more = tile + step < last;
-        const uint16_t *ctr = s_img + (ty + kHalo) * PW + (tx + kHalo);
-        PairAcc acc0, acc1, acc2;
-        acc0.clear(); acc1.clear(); acc2.clear();
-        for (int pv = 0; pv < P; ++pv) {
-            const int ph = __builtin_amdgcn_readfirstlane(pv);
-            const int m = mode_of(ph);
-            // my DMA pieces have landed; after the barrier everyone's have, the image tile is visible and
-            // every wave has left the previous phase (so the buffer it read is free)
-#if defined(MULUT_PROFILE)
-            const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
-#endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-#if defined(MULUT_PROFILE)
-            const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
-            pt_bar += pt2 - pt1;
-#endif
-            if ((cur ? held1 : held0) != m) cur ^= 1;
-            {   // bring the next DIFFERENT band into the other buffer (at most two phases ahead)
-                const int q1 = ph + 1, q2 = ph + 2;
-                const int n1 = q1 < P ? mode_of(q1) : (more ? mode_of(q1 - P) : -1);
-                const int n2 = q2 < P ? mode_of(q2) : (more ? mode_of(q2 - P) : -1);
-                const int nxt = n1 != m ? n1 : n2;
-                const int other = cur ? held0 : held1;
-                if (nxt >= 0 && nxt != m && other != nxt) {
-                    band_dma_untracked<NT>((const uint8_t *)b.band[nxt], s_band + (cur ^ 1) * kBandXBytes);
-                    if (cur) held0 = nxt; else held1 = nxt;
-                }
-            }
-            const uint8_t *band = s_band + cur * kBandXBytes;
-            if (ph == M) {   // rotations 1,3 done: rotation-1 order -> block order, in registers
-                acc0.to_block_order();
-                acc1.to_block_order();
-                acc2.to_block_order();
-            }
-            if (valid) {
-                const void *lut = a.lut[m];
-                const int r = ph < M ? 1 : 0;
-                int dy, dx;
-                sample_offset(r, a.di[m][0], a.dj[m][0], dy, dx); const int o0 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
-                sample_offset(r, a.di[m][1], a.dj[m][1], dy, dx); const int o1 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
-                sample_offset(r, a.di[m][2], a.dj[m][2], dy, dx); const int o2 = __builtin_amdgcn_readfirstlane(dy * PW + dx);
-                // pixel codes of all channels first (one LDS round trip per phase), then the passes
-                uint32_t ca[3], pb[3], pc[3], pd[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const uint16_t *cc = ctr + (c < a.C ? c : 0) * PH * PW;
-                    ca[c] = cc[0];
-                    pb[c] = cc[o0] | ((uint32_t)cc[-o0] << 16);
-                    pc[c] = cc[o1] | ((uint32_t)cc[-o1] << 16);
-                    pd[c] = cc[o2] | ((uint32_t)cc[-o2] << 16);
-                }
-                BandPair bp0, bp1, bp2;
-                simplex4_band_pair_code(ca[0], pb[0], pc[0], pd[0], bp0);
-                simplex4_band_pair_code(ca[1], pb[1], pc[1], pd[1], bp1);
-                simplex4_band_pair_code(ca[2], pb[2], pc[2], pd[2], bp2);
-                // pin the finished index math in front of the branch (otherwise parts of it are sunk into the
-                // fast block and their inputs are carried across in scratch)
-                auto pin = [](BandPair &bp) {
-                    asm volatile("" : "+v"(bp.addr[0]), "+v"(bp.addr[1]), "+v"(bp.addr[2]), "+v"(bp.addr[3]), "+v"(bp.addr[4]));
-                    asm volatile("" : "+v"(bp.w[0]), "+v"(bp.w[1]), "+v"(bp.w[2]), "+v"(bp.w[3]), "+v"(bp.w[4]));
-                };
-                pin(bp0);
-                pin(bp1);
-                pin(bp2);
-                int slow = 0;
-                if (a.C == 3 && __all((bp0.t_band | bp1.t_band | bp2.t_band) == 0u)) {
-                    rows_y6<MULUT_Y6_AHEAD>(band, bp0, bp1, bp2, acc0, acc1, acc2);
-                } else {
-                    slow = 1;
-                    pair_y(band, lut, ctr, o0, o1, o2, acc0);
-                    if (a.C > 1) pair_y(band, lut, ctr + PH * PW, o0, o1, o2, acc1);
-                    if (a.C > 2) pair_y(band, lut, ctr + 2 * PH * PW, o0, o1, o2, acc2);
-                }
-                (void)slow;
-#if defined(MULUT_PROFILE)
-                pt_slow += (unsigned)__builtin_amdgcn_readfirstlane(slow);
-#endif
-            }
-#if defined(MULUT_PROFILE)
-            pt_cmp += __builtin_amdgcn_s_memtime() - pt2;
-#endif
         }
 #if defined(MULUT_PROFILE)
         const unsigned long long pt3 = __builtin_amdgcn_s_memtime();
@@ -1401,12 +1084,11 @@ __global__ void __launch_bounds__(TW *TH) stage_bandy_kernel(StageArgs a, BandAr
         pt_epi += __builtin_amdgcn_s_memtime() - pt3;
 #endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA piece may outlive the workgroup
 #if defined(MULUT_PROFILE)
     if ((threadIdx.x & 63) == 0) {
         unsigned long long *dst = (unsigned long long *)(a.out.p + (long long)a.N * a.out.sN) + ((size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * 8;
         dst[0] = __builtin_amdgcn_s_memtime() - pt_begin;
-        dst[1] = pt_load; dst[2] = pt_bar; dst[3] = pt_cmp; dst[4] = pt_epi; dst[5] = pt_slow;
+        dst[1] = pt_load; dst[2] = pt_bar; dst[3] = prof.t_fast; dst[4] = pt_epi; dst[5] = prof.n_slow; dst[6] = prof.t_slow; dst[7] = prof.n_fast;
     }
 #endif
 }
@@ -1416,9 +1098,9 @@ const char *stage_bandx_name(int out_mode) {
                                                                                                : "stage_bandx_kernel<generic>";
 }
 
-template <int OUT, int VARIANT>
+template <int OUT>
 static hipError_t launch_bandx_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
-    auto kern = VARIANT ? stage_bandy_kernel<OUT, KB_TW, KB_TH> : stage_bandx_kernel<OUT, KB_TW, KB_TH>;
+    auto kern = stage_bandx_kernel<OUT, KB_TW, KB_TH>;
     const size_t lds = 2 * (size_t)kBandXBytes + 2 * (size_t)(((2 * 3 * (KB_TH + 2 * kHalo) * (KB_TW + 2 * kHalo) + 15) / 16) * 16);
     static bool attr_set[64] = {};
     int dev = 0;
@@ -1435,16 +1117,11 @@ static hipError_t launch_bandx_t(const StageArgs &a, const BandArgs &b, int num_
     return hipGetLastError();
 }
 
-hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st, int variant) {
+hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st) {
     if (a.C > 3 || a.M > 3) return hipErrorInvalidValue;
-    if (variant) {
-        if (out_mode == kOutPlanarU4) return launch_bandx_t<kOutPlanarU4, 1>(a, b, num_cus, st);
-        if (out_mode == kOutPackedRGBU4 && a.C == 3) return launch_bandx_t<kOutPackedRGBU4, 1>(a, b, num_cus, st);
-        return launch_bandx_t<kOutGeneric, 1>(a, b, num_cus, st);
-    }
-    if (out_mode == kOutPlanarU4) return launch_bandx_t<kOutPlanarU4, 0>(a, b, num_cus, st);
-    if (out_mode == kOutPackedRGBU4 && a.C == 3) return launch_bandx_t<kOutPackedRGBU4, 0>(a, b, num_cus, st);
-    return launch_bandx_t<kOutGeneric, 0>(a, b, num_cus, st);
+    if (out_mode == kOutPlanarU4) return launch_bandx_t<kOutPlanarU4>(a, b, num_cus, st);
+    if (out_mode == kOutPackedRGBU4 && a.C == 3) return launch_bandx_t<kOutPackedRGBU4>(a, b, num_cus, st);
+    return launch_bandx_t<kOutGeneric>(a, b, num_cus, st);
 }
 
 }  // namespace mulut

@@ -23,7 +23,7 @@ from mulut_amd.synth import natural_frames, noise_frames, real_frames  # noqa: E
 
 
 def build_variant(name):
-    name = name.split("~")[0].split("@")[0]
+    name = name.split("@")[0]
     if name == "base":
         return _native.build()
     out_dir = os.path.join(ROOT, "build", "variants")
@@ -55,13 +55,8 @@ def main():
     engines = {}
     for n in names:
         e = MuLUTEngine(0, lib_path=libs[n]).configure(2, "sdy", 4, 4).set_lut_dict(luts)
-        if "~" in n:                    # name[@kernel[:threshold]]~bandx_variant
-            n_, v = n.split("~")
-            e.set_tuning("bandx_variant", int(v))
-        else:
-            n_ = n
-        if "@" in n_:
-            sel = n_.split("@")[1]
+        if "@" in n:
+            sel = n.split("@")[1]
             e.set_tuning("final_stage_kernel", int(sel.split(":")[0]))
             if ":" in sel:
                 e.set_tuning("hybrid_oob_per_1024", int(sel.split(":")[1]))
