@@ -132,6 +132,17 @@ int mulut_ft_stage_backward(int device, const float *const *weights_q, const cha
                             const float *grad_out, int B, int C, int H, int W, float *const *grad_wq, float *grad_x,
                             void *stream);
 
+/* ---- device-side evaluation (not on the inference path) ---------------------------------------------------
+ * Y-channel PSNR and SSIM of a super-resolved frame against its ground truth, exactly as the test script scores
+ * them (sr/4_test_lut.py:313-315): y = _rgb2ycbcr(img)[:,:,0] (common/utils.py:42-60), PSNR with `shave` border
+ * pixels removed and a float32 difference (:63-72), SSIM with the 11x11 sigma-1.5 Gaussian over 'valid' windows
+ * in float64 (:75-101).  gt_hwc / out_hwc: device uint8 [H][W][3]; ws: device scratch of at least
+ * mulut_eval_ws_doubles(H, W) doubles.  Synchronises `stream` and writes the two host doubles.
+ * Errors: MULUT_ESHAPE (image smaller than the window or the shave), MULUT_EWORKSPACE. */
+long long mulut_eval_ws_doubles(int H, int W);
+int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int W, int shave, double *ws, long long ws_doubles,
+                 double *psnr, double *ssim, void *stream);
+
 /* Tuning knobs (never change results).  "final_stage_kernel": 0 = auto (hybrid when scale 4 and <= 3
  * modes), 1 = full-table gather kernel, 2 = compact LDS-band kernel, 3 = expanded LDS-band kernel, 4 = hybrid (a
  * per-tile statistic sends smooth 64x16 tiles to the band kernel and detailed ones to the full-table kernel).

@@ -8,7 +8,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 _LIBDIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(_LIBDIR, "libmulut_hip.so")
-SOURCES = ["mulut_kernels.hip", "mulut_capi.hip", "mulut_ft.hip"]
+SOURCES = ["mulut_kernels.hip", "mulut_capi.hip", "mulut_ft.hip", "mulut_eval.hip"]
 HEADERS = ["mulut_core.h", "mulut_kernels.h", os.path.join("..", "..", "include", "mulut.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall"]
 
@@ -18,6 +18,7 @@ EXPORTS = [
     "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage", "mulut_pipeline",
     "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing", "mulut_last_stage_ms",
     "mulut_set_tuning", "mulut_kernel_name", "mulut_ft_stage_forward", "mulut_ft_stage_backward",
+    "mulut_eval_ws_doubles", "mulut_eval_y",
 ]
 
 _libs = {}
@@ -85,6 +86,11 @@ def load(path=None):
     L.mulut_ft_stage_forward.argtypes = [i, p, c_char_p, i, i, p, i, i, i, i, p, p]
     L.mulut_ft_stage_backward.argtypes = [i, p, c_char_p, i, i, p, p, i, i, i, i, p, p, p]
     L.mulut_kernel_name.restype = c_char_p
+    L.mulut_eval_ws_doubles.argtypes = [i, i]
+    L.mulut_eval_ws_doubles.restype = ctypes.c_longlong
+    L.mulut_eval_y.argtypes = [i, p, p, i, i, i, p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_double),
+                               ctypes.POINTER(ctypes.c_double), p]
+    L.mulut_eval_y.restype = i
     for name in ("mulut_create", "mulut_destroy", "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage",
                  "mulut_pipeline", "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing",
                  "mulut_last_stage_ms", "mulut_set_tuning", "mulut_ft_stage_forward", "mulut_ft_stage_backward"):

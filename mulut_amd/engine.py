@@ -179,6 +179,21 @@ class MuLUTEngine:
             self._check(n)
         return [float(buf[k]) for k in range(n)]
 
+    def eval_y(self, gt_hwc, out_hwc, shave):
+        """(PSNR, SSIM) on the Y channel of two device uint8 HWC RGB images, as sr/4_test_lut.py:313-315 scores a result
+        (common/utils.py:42-101) -- computed on the device, only two doubles come back."""
+        gt = self._dev_u8(gt_hwc, "gt")
+        out = self._dev_u8(out_hwc, "out")
+        if gt.dim() != 3 or gt.shape[2] != 3 or gt.shape != out.shape:
+            raise ValueError("eval_y wants two HWC RGB images of one shape, got %s and %s" % (tuple(gt.shape), tuple(out.shape)))
+        H, W = int(gt.shape[0]), int(gt.shape[1])
+        n = int(self._lib.mulut_eval_ws_doubles(H, W))
+        ws = torch.empty(n, dtype=torch.float64, device=gt.device)
+        psnr, ssim = ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.mulut_eval_y(self.device.index, gt.data_ptr(), out.data_ptr(), H, W, int(shave), ws.data_ptr(), n,
+                                           ctypes.byref(psnr), ctypes.byref(ssim), self._stream()))
+        return psnr.value, ssim.value
+
     def set_tuning(self, key, value):
         """Performance knobs that never change results, e.g. ("final_stage_kernel", 1)."""
         self._check(self._lib.mulut_set_tuning(self._h, key.encode(), int(value)))

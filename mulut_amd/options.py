@@ -37,6 +37,8 @@ class TestOptions:
         # additions
         parser.add_argument('--device', type=int, default=0, help="GPU index")
         parser.add_argument('--datasets', type=str, default='Set5', help="comma separated (reference: ['Set5'])")
+        parser.add_argument('--deviceMetrics', action='store_true', default=False,
+                            help="score PSNR/SSIM on the GPU (same numbers; saves the host-side SciPy convolutions)")
         parser.add_argument('--saveCode', action='store_true', default=False,
                             help="copy *.py under cwd into <expDir>/code like the reference's parse()")
         return parser

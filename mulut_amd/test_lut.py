@@ -22,7 +22,9 @@ from .options import TestOptions
 class eltr:
     """Same name and role as the reference's evaluator class (sr/4_test_lut.py:240)."""
 
-    def __init__(self, dataset, opt, engine):
+    def __init__(self, dataset, opt, engine, device_metrics=None):
+        # device_metrics: score on the GPU (engine.eval_y) instead of NumPy/SciPy on the host; same numbers
+        self.device_metrics = bool(getattr(opt, "deviceMetrics", False)) if device_metrics is None else bool(device_metrics)
         folder = os.path.join(opt.testDir, dataset, 'HR')
         files = os.listdir(folder)
         files.sort()
@@ -42,12 +44,15 @@ class eltr:
                                                                       np.mean(arr[:, 1])))
         return arr
 
-    def super_resolve(self, img_lr):
-        """uint8 HWC (or HW gray -> replicated to 3 channels, :268-270) -> uint8 HWC."""
+    def super_resolve_device(self, img_lr):
+        """uint8 HWC (or HW gray -> replicated to 3 channels, :268-270) -> uint8 HWC tensor on the GPU."""
         if img_lr.ndim == 2:
             img_lr = np.stack([img_lr] * 3, axis=2)
         x = torch.from_numpy(np.ascontiguousarray(img_lr)).to(self.engine.device)
-        return self.engine.pipeline(x).cpu().numpy()
+        return self.engine.pipeline(x)
+
+    def super_resolve(self, img_lr):
+        return self.super_resolve_device(img_lr).cpu().numpy()
 
     def _worker(self, i):
         opt = self.opt
@@ -57,10 +62,14 @@ class eltr:
         img_gt = modcrop(img_gt, opt.scale)
         if img_gt.ndim == 2:
             img_gt = np.stack([img_gt] * 3, axis=2)
-        img_out = self.super_resolve(img_lr)
+        dev_out = self.super_resolve_device(img_lr)
+        img_out = dev_out.cpu().numpy()
         Image.fromarray(img_out).save(os.path.join(
             self.result_path, '{}_{}_{}bit.png'.format(self.files[i].split('/')[-1][:-4], opt.lutName,
                                                        8 - opt.interval)))
+        if self.device_metrics:
+            gt = torch.from_numpy(np.ascontiguousarray(img_gt)).to(self.engine.device)
+            return list(self.engine.eval_y(gt, dev_out, opt.scale))
         y_gt, y_out = rgb2ycbcr(img_gt)[:, :, 0], rgb2ycbcr(img_out)[:, :, 0]
         return [psnr(y_gt, y_out, opt.scale), ssim(y_gt, y_out)]
 

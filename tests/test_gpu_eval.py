@@ -1,0 +1,112 @@
+"""Device-side evaluation (mulut_eval_y) and the fork's single-image API (mulut_amd/single.py) on the GPU, against
+values produced by the reference's common/utils.py and against the CLI path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+from mulut_amd import MuLUTEngine, MuLUTError  # noqa: E402
+from mulut_amd.metrics import modcrop  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return MuLUTEngine(0)
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(GOLDEN, "metrics_fixtures.npz"))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_eval_random_pairs_match_reference(eng, fx):
+    for n in sorted({k.rsplit("/", 1)[0] for k in fx.files if k.startswith("rand/")}):
+        shave = int(n.rsplit("_s", 1)[1])
+        p, s = eng.eval_y(dev(fx[n + "/gt"]), dev(fx[n + "/out"]), shave)
+        assert p == pytest.approx(fx[n + "/score"][0], abs=1e-4), n      # float32 mean: summation order differs
+        assert s == pytest.approx(fx[n + "/score"][1], abs=1e-10), n
+
+
+def test_eval_set5_matches_reference_and_summary_line(eng, fx):
+    vals = []
+    for k in sorted(k for k in fx.files if k.startswith("set5/")):
+        stem = k.split("/")[1]
+        out = np.array(Image.open(os.path.join(GOLDEN, "Set5", "ref_out", stem + "_LUT_ft_4bit.png")))
+        gt = modcrop(np.array(Image.open(os.path.join(GOLDEN, "Set5", "HR", stem + ".png"))), 4)
+        p, s = eng.eval_y(dev(gt), dev(out), 4)
+        assert p == pytest.approx(fx[k][0], abs=1e-4) and s == pytest.approx(fx[k][1], abs=1e-10), stem
+        vals.append((p, s))
+    assert "{:.2f} {:.4f}".format(*np.mean(vals, axis=0)) == "30.61 0.8656"
+
+
+def test_eval_identical_images_and_errors(eng):
+    a = dev(np.random.default_rng(0).integers(0, 256, (40, 50, 3), dtype=np.uint8))
+    p, s = eng.eval_y(a, a, 4)
+    assert p == float("inf") and s == pytest.approx(1.0, abs=1e-12)       # reference: log10(255/0) -> inf
+    with pytest.raises(MuLUTError):
+        eng.eval_y(a[:10, :10].contiguous(), a[:10, :10].contiguous(), 2)  # smaller than the 11x11 window
+    with pytest.raises(MuLUTError):
+        eng.eval_y(a, a, 20)                                              # nothing left after shaving
+    with pytest.raises(ValueError):
+        eng.eval_y(a, a[:, :40].contiguous(), 4)
+
+
+def _exp_dir(tmp_path):
+    exp = tmp_path / "models" / "sr_x2sdy"
+    exp.mkdir(parents=True)
+    for fn in os.listdir(os.path.join(GOLDEN, "luts")):
+        os.symlink(os.path.join(GOLDEN, "luts", fn), exp / fn)
+    return str(exp)
+
+
+def test_cli_with_device_metrics_prints_the_same_line(tmp_path, capsys):
+    from mulut_amd import test_lut
+    test_dir = tmp_path / "SRBenchmark"
+    (test_dir / "Set5").mkdir(parents=True)
+    os.symlink(os.path.join(GOLDEN, "Set5", "HR"), test_dir / "Set5" / "HR")
+    os.symlink(os.path.join(GOLDEN, "Set5", "LR_bicubic"), test_dir / "Set5" / "LR_bicubic")
+    test_lut.main(["--stages", "2", "--modes", "sdy", "-e", _exp_dir(tmp_path), "--testDir", str(test_dir),
+                   "--resultRoot", str(tmp_path / "results"), "--deviceMetrics"])
+    assert capsys.readouterr().out.strip().splitlines()[-1] == "Dataset Set5 | AVG LUT PSNR: 30.61 SSIM: 0.8656"
+
+
+def test_single_image_api(tmp_path, fx):
+    from mulut_amd import single
+    exp = _exp_dir(tmp_path)
+    lr = os.path.join(GOLDEN, "Set5", "LR_bicubic", "X4", "bird.png")
+    hr = os.path.join(GOLDEN, "Set5", "HR", "bird.png")
+    want = np.array(Image.open(os.path.join(GOLDEN, "Set5", "ref_out", "bird_LUT_ft_4bit.png")))
+    # test_single_image_direct: file in, file out
+    out1 = str(tmp_path / "o" / "bird_sr.png")
+    assert single.test_single_image_direct(lr, out1, stages=2, modes="sdy", scale=4, exp_dir=exp) == out1
+    assert np.array_equal(np.array(Image.open(out1)), want)
+    # process_single_image / _with_gt on an explicit options object
+    opt = single.create_simple_options(stages=2, modes="sdy", scale=4, exp_dir=exp, lut_name="LUT_ft")
+    assert opt.modes == ["s", "d", "y"] and opt.resultRoot == "../temp_output"
+    luts = single.load_luts(opt)
+    assert single.process_single_image(lr, str(tmp_path / "p.png"), opt, luts) == (str(tmp_path / "p.png"), None, None)
+    for on_device in (False, True):
+        path, p, s = single.process_single_image_with_gt(lr, hr, str(tmp_path / "q.png"), opt, luts, device_metrics=on_device)
+        assert np.array_equal(np.array(Image.open(path)), want)
+        assert p == pytest.approx(fx["set5/bird"][0], abs=1e-4) and s == pytest.approx(fx["set5/bird"][1], abs=1e-10)
+    # errors as in the fork: missing input, missing table
+    with pytest.raises(FileNotFoundError):
+        single.process_single_image(str(tmp_path / "nope.png"), str(tmp_path / "r.png"), opt, luts)
+    with pytest.raises(FileNotFoundError):
+        single.load_luts(single.create_simple_options(stages=2, modes="sdy", scale=4, exp_dir=exp))   # lut_name "MuLUT"
+    # gray input is replicated to three channels (sr/5_test_lut.py:262-265)
+    g = np.array(Image.open(lr).convert("L"))
+    Image.fromarray(g).save(tmp_path / "gray.png")
+    single.process_single_image(str(tmp_path / "gray.png"), str(tmp_path / "gray_sr.png"), opt, luts)
+    got = np.array(Image.open(tmp_path / "gray_sr.png"))
+    assert got.shape == (g.shape[0] * 4, g.shape[1] * 4, 3) and np.array_equal(got[..., 0], got[..., 1])
