@@ -110,3 +110,30 @@ def test_single_image_api(tmp_path, fx):
     single.process_single_image(str(tmp_path / "gray.png"), str(tmp_path / "gray_sr.png"), opt, luts)
     got = np.array(Image.open(tmp_path / "gray_sr.png"))
     assert got.shape == (g.shape[0] * 4, g.shape[1] * 4, 3) and np.array_equal(got[..., 0], got[..., 1])
+
+
+def test_transfer_on_gpu_matches_reference_tables_and_feeds_the_pipeline(tmp_path, capsys):
+    """sr/2_transfer_to_lut.py twin end to end on the GPU: shipped checkpoint -> int8 tables (within the rounding bar
+    of tests/test_transfer_cpu.py) -> `--lutName LUT` inference on Set5 (the not-yet-fine-tuned tables score a little
+    below the fine-tuned 30.61 dB)."""
+    import shutil
+    from mulut_amd import test_lut, transfer_to_lut as T
+    fxt = np.load(os.path.join(GOLDEN, "transfer_fixtures.npz"))
+    exp = tmp_path / "models" / "sr_x2sdy"
+    exp.mkdir(parents=True)
+    shutil.copyfile(os.path.join(GOLDEN, "Model_200000.pth"), exp / "Model_200000.pth")
+    tabs = T.main(["--stages", "2", "--modes", "sdy", "-e", str(exp)])
+    for key, t in tabs.items():
+        rows = t.reshape(t.shape[0], -1)[fxt["idx"]].astype(np.int32)
+        diff = np.abs(rows - fxt["shipped/" + key + "/rows"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).mean() <= 1e-4, key
+        assert os.path.exists(exp / ("LUT_x4_4bit_int8_%s.npy" % key))
+    test_dir = tmp_path / "SRBenchmark"
+    (test_dir / "Set5").mkdir(parents=True)
+    os.symlink(os.path.join(GOLDEN, "Set5", "HR"), test_dir / "Set5" / "HR")
+    os.symlink(os.path.join(GOLDEN, "Set5", "LR_bicubic"), test_dir / "Set5" / "LR_bicubic")
+    capsys.readouterr()
+    res = test_lut.main(["--stages", "2", "--modes", "sdy", "-e", str(exp), "--testDir", str(test_dir),
+                         "--resultRoot", str(tmp_path / "results"), "--lutName", "LUT", "--deviceMetrics"])
+    psnr = float(np.mean(res["Set5"][:, 0]))
+    assert 30.0 < psnr < 30.7, psnr
