@@ -72,11 +72,37 @@
 #define A_BFI(D) "v_bfi_b32 " D ", " D ", %8, %9\n"
 #define A_SAD(D) "v_sad_u8 " D ", " D ", %8, %9\n"
 #define A_MQSAD(D) "v_msad_u8 " D ", " D ", %8, %9\n"
+#define A_MINF(D) "v_min_f32 " D ", " D ", %8\n"
+#define A_MAXF(D) "v_max_f32 " D ", " D ", %8\n"
+#define A_ADDF(D) "v_add_f32 " D ", " D ", %8\n"
+#define A_SUBF(D) "v_sub_f32 " D ", " D ", %8\n"
+#define A_MED3F(D) "v_med3_f32 " D ", " D ", %8, %9\n"
+#define A_MIN3F(D) "v_min3_f32 " D ", " D ", %8, %9\n"
+#define A_CVTU(D) "v_cvt_u32_f32 " D ", " D "\n"
+#define A_CVTUB0(D) "v_cvt_f32_ubyte0 " D ", " D "\n"
+#define A_FLOORF(D) "v_floor_f32 " D ", " D "\n"
+#define A_FRACTF(D) "v_fract_f32 " D ", " D "\n"
+#define A_OR(D) "v_or_b32 " D ", " D ", %8\n"
+#define A_XOR(D) "v_xor_b32 " D ", " D ", %8\n"
+#define A_LSHL(D) "v_lshlrev_b32 " D ", 4, " D "\n"
+#define A_SUB(D) "v_sub_u32 " D ", " D ", %8\n"
+#define A_ASHR(D) "v_ashrrev_i32 " D ", 4, " D "\n"
+#define A_MINI(D) "v_min_i32 " D ", " D ", %8\n"
+#define A_MINU16(D) "v_min_u16 " D ", " D ", %8\n"
+#define A_ADDU16(D) "v_add_u16 " D ", " D ", %8\n"
+#define A_MULF16(D) "v_mul_f16 " D ", " D ", %8\n"
+#define A_MINF16(D) "v_min_f16 " D ", " D ", %8\n"
+#define A_PKMINF16(D) "v_pk_min_f16 " D ", " D ", %8\n"
+#define A_PKADDF16(D) "v_pk_add_f16 " D ", " D ", %8\n"
+#define A_PKFMAF16(D) "v_pk_fma_f16 " D ", " D ", %8, %9\n"
+#define A_BFIOR(D) "v_bitop3_b32 " D ", " D ", %8, %9 bitop3:0xc8\n"
 
 #define OPS(X)                                                                                                       \
     X(ADD) X(AND) X(LSHR) X(MIN) X(MAX) X(MIN3) X(MED3) X(MAD24) X(MUL24) X(MULLO) X(MULHI) X(PERM) X(DOT4) X(PKMAD)   \
     X(PKMIN) X(PKADD) X(BFE) X(LSHLOR) X(ANDOR) X(ADD3) X(LSHLADD) X(SUBSDWA) X(CVTF) X(CVTFSDWA) X(RNDNE) X(MULF)    \
-    X(FMA) X(CVTPK) X(ALIGN) X(CNDMASK) X(MOV) X(XAD) X(MADI24) X(BFI) X(SAD) X(MQSAD)
+    X(FMA) X(CVTPK) X(ALIGN) X(CNDMASK) X(MOV) X(XAD) X(MADI24) X(BFI) X(SAD) X(MQSAD)              \
+    X(MINF) X(MAXF) X(ADDF) X(SUBF) X(MED3F) X(MIN3F) X(CVTU) X(CVTUB0) X(FLOORF) X(FRACTF) X(OR) X(XOR) X(LSHL) X(SUB) X(ASHR)   \
+    X(MINI) X(MINU16) X(ADDU16) X(MULF16) X(MINF16) X(PKMINF16) X(PKADDF16) X(PKFMAF16) X(BFIOR)
 
 #define MK(N) DEFKERNEL(N, A_##N)
 OPS(MK)
