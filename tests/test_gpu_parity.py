@@ -357,3 +357,14 @@ def test_hybrid_final_stage_variants_agree_and_capture(eng, shipped_luts):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+def test_randomised_configurations_vs_oracle():
+    """60 seeded random configurations (stages, mode strings, scales, channels, layouts, strips, kernel variants,
+    content and table kinds) through tools/fuzz_parity.py; the long runs are logged in profiles/."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--cases", "60", "--seed", "123"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
