@@ -146,7 +146,9 @@ int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int
 /* Tuning knobs (never change results).  "final_stage_kernel": 0 = auto (hybrid when scale 4 and <= 3
  * modes), 1 = full-table gather kernel, 2 = compact LDS-band kernel, 3 = expanded LDS-band kernel, 4 = hybrid (a
  * per-tile statistic sends smooth 64x16 tiles to the band kernel and detailed ones to the full-table kernel).
- * "hybrid_oob_per_1024": tile threshold (sites out of band per 1024, default 128).  Unknown key or value: MULUT_EINVAL. */
+ * "hybrid_oob_per_1024": tile threshold (sites out of band per 1024, default 128).  "first_stage_kernel" (stages with
+ * 1-byte rows): 0 = window kernel (four adjacent pixels per thread, neighbours read as dwords), 1 = one LDS read per
+ * neighbour.  Unknown key or value: MULUT_EINVAL. */
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value);
 
 /* Name of the kernel variant used for the final / non-final stage (for profiles). */

@@ -38,6 +38,7 @@ struct mulut_ctx {
     int f32_ok[2] = {0, 0}; // float epilogue proven exact for the [non-final, final] divisor
     uint32_t *verdict = nullptr;   // per-tile smooth/detailed verdicts of the hybrid final stage
     size_t verdict_tiles = 0;
+    int first_kernel = 0;   // 1-byte-row stages: 0 window kernel, 1 the original one-site-per-read kernel
     int hybrid_oob_per_1024 = 128; // a tile is "detailed" when more than 1/8 of its (sampled) sites leave the band
     bool timing = false;
     hipEvent_t ev[MULUT_MAX_STAGES + 1] = {};
@@ -294,7 +295,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.tiles_x = (W + tw - 1) / tw;
     a.tiles_y = (oy1 - oy0 + th - 1) / th;
     if (u == 1) {
-        HIP_TRY(ctx, launch_stage_u1(a, st));
+        HIP_TRY(ctx, launch_stage_u1(a, st, ctx->first_kernel));
         return MULUT_OK;
     }
     int mode = kOutGeneric;
@@ -460,6 +461,11 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "final_stage_kernel")) {
         if (value < 0 || value > 4) return MULUT_EINVAL;
         ctx->final_kernel = value;
+        return MULUT_OK;
+    }
+    if (!strcmp(key, "first_stage_kernel")) {
+        if (value < 0 || value > 1) return MULUT_EINVAL;
+        ctx->first_kernel = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "hybrid_oob_per_1024")) {

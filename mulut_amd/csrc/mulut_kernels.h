@@ -66,7 +66,8 @@ enum K2Out { kOutGeneric = 0, kOutPlanarU4 = 1, kOutPackedRGBU4 = 2 };
 
 hipError_t launch_pass(const PassArgs &a, hipStream_t st);
 // non-final (or u == 1 final) stage: tables staged in LDS, one byte out per site
-hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st);
+// variant 0: window kernel (four adjacent pixels per thread, neighbours from registers), 1: one site per LDS read
+hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant);
 // final stage with u in {2,3,4}: u*u bytes out per site
 hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t st);
 // final stage, u == 4, M <= 3: band tables resident in LDS, persistent workgroups

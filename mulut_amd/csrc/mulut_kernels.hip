@@ -250,23 +250,146 @@ __global__ void __launch_bounds__(NT) stage_u1_kernel(StageArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K1-window: the same stage with the PIXEL reads taken out of the LDS instruction stream.  The LDS unit
+// retires about one sub-dword read per 6.5 cycles per CU whatever the bank spread, and stage_u1_kernel issues
+// 8 of them per pass (3 neighbours + 5 table bytes): it is bound by their count (tools/experiments/README.md).
+// Here a thread owns FOUR horizontally adjacent pixels of a row; the 5 x 8-byte window around them (all 24
+// neighbours of all four pixels, every mode, every rotation) is fetched as ten aligned ds_read_b32 per channel
+// and mode, and every key nibble is a v_bfe_u32 at a compile-time bit position -- the mode pattern is a
+// template parameter of the per-mode body, chosen by a scalar switch.  444 neighbour-byte reads per thread
+// and tile become 90 dword reads; the 5 table-byte gathers per pass stay.
+// ------------------------------------------------------------------------------------------
+constexpr int kPatDi[3][3] = {{0, 1, 1}, {0, 2, 2}, {1, 1, 2}};   // s, d, y: row offsets of keys b, c, d (pattern_offsets)
+constexpr int kPatDj[3][3] = {{1, 0, 1}, {2, 0, 2}, {1, 2, 1}};
+constexpr int rot_dy(int r, int di, int dj) { return r == 0 ? di : r == 1 ? dj : r == 2 ? -di : -dj; }   // sample_offset
+constexpr int rot_dx(int r, int di, int dj) { return r == 0 ? dj : r == 1 ? -di : r == 2 ? -dj : di; }
+
+template <int ROW, int COL>
+__device__ __forceinline__ int win_byte(const uint32_t (&win)[5][2]) {
+    static_assert(ROW >= 0 && ROW < 5 && COL >= 0 && COL < 8, "window is 5 rows x 8 bytes");
+    return (int)((win[ROW][COL >> 2] >> (8 * (COL & 3))) & 0xFFu);
+}
+
+// One mode over the thread's 3 x 4 sites.  Both loops are real loops (one pixel body per pattern in the binary,
+// and nothing of a later pixel can be scheduled into an earlier one): the pixel loop shifts the window left by one
+// byte per step so that the current pixel always sits at window column 2, and the accumulators rotate through
+// fixed registers -- four steps per channel, three channel groups -- instead of being indexed.
+template <int PAT, int PW, int PH>
+__device__ __forceinline__ void u1w_mode(const int8_t *s_lut, const uint8_t *s_img, int ty, int x4, int C, int (&acc)[12]) {
+    int c = 0;
+#pragma clang loop unroll(disable)
+    for (; c < C; ++c) {
+        // window row q = image row y - 2 + q = tile row ty + q; byte j = pixel x4 - 2 + j = tile column x4 + j
+        const uint32_t *row = (const uint32_t *)(s_img + c * (PH * PW) + ty * PW + x4);
+        uint32_t win[5][2];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            win[q][0] = row[q * (PW / 4)];
+            win[q][1] = row[q * (PW / 4) + 1];
+        }
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < 4; ++i) {
+            const int va = win_byte<2, 2>(win);
+            int idx[4][5], w[4][5];
+            static_for<0, 4>([&](auto RR) {
+                constexpr int r = RR;
+                const int vb = win_byte<2 + rot_dy(r, kPatDi[PAT][0], kPatDj[PAT][0]), 2 + rot_dx(r, kPatDi[PAT][0], kPatDj[PAT][0])>(win);
+                const int vc = win_byte<2 + rot_dy(r, kPatDi[PAT][1], kPatDj[PAT][1]), 2 + rot_dx(r, kPatDi[PAT][1], kPatDj[PAT][1])>(win);
+                const int vd = win_byte<2 + rot_dy(r, kPatDi[PAT][2], kPatDj[PAT][2]), 2 + rot_dx(r, kPatDi[PAT][2], kPatDj[PAT][2])>(win);
+                simplex4(va, vb, vc, vd, idx[r], w[r]);
+            });
+            int lv[4][5];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) lv[r][j] = (int)s_lut[idx[r][j]];
+            int sum = acc[0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) sum += w[r][j] * lv[r][j];
+            acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = acc[3]; acc[3] = sum;       // next pixel's accumulator to slot 0
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {                                            // window one pixel to the left
+                win[q][0] = __builtin_amdgcn_alignbit(win[q][1], win[q][0], 8);
+                win[q][1] >>= 8;
+            }
+        }
+        // next channel's four accumulators to slots 0..3
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int t = acc[k]; acc[k] = acc[4 + k]; acc[4 + k] = acc[8 + k]; acc[8 + k] = t; }
+    }
+#pragma clang loop unroll(disable)
+    for (; c < 3; ++c) {   // fewer than three channels: finish the cycle so that slot order is restored
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int t = acc[k]; acc[k] = acc[4 + k]; acc[4 + k] = acc[8 + k]; acc[8 + k] = t; }
+    }
+}
+
+template <int TW, int TH, int NT>
+__global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
+    constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
+    static_assert(TW * TH == 4 * NT && PW % 4 == 0, "four adjacent pixels per thread, dword-aligned tile rows");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int8_t *s_lut = (const int8_t *)smem;
+    uint8_t *s_img = smem + kU1TableBytes;
+
+    int n, y0, x0;
+    decode_tile(a, xcd_remap(blockIdx.x, gridDim.x), n, y0, x0, TW, TH);
+    load_tile<TW, TH, NT>(a, n, y0, x0, s_img);
+    const int x4 = (int)(threadIdx.x % (TW / 4)) * 4, ty = (int)(threadIdx.x / (TW / 4));
+    int acc[12];   // [channel][pixel]
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0;
+
+    for (int mv = 0; mv < a.M; ++mv) {
+        const int m = __builtin_amdgcn_readfirstlane(mv);
+        __syncthreads();  // tile filled (m == 0) / everyone done with the previous table
+        {
+            const uint4 *src = (const uint4 *)a.lut[m];
+            uint4 *dst = (uint4 *)smem;
+            for (int i = threadIdx.x; i < kU1TableBytes / 16; i += NT) dst[i] = src[i];
+        }
+        __syncthreads();
+        // pattern of this mode from its first key offset: s (0,1), d (0,2), y (1,1) -- scalar
+        const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
+        if (pat == 0) u1w_mode<0, PW, PH>(s_lut, s_img, ty, x4, a.C, acc);
+        else if (pat == 1) u1w_mode<1, PW, PH>(s_lut, s_img, ty, x4, a.C, acc);
+        else u1w_mode<2, PW, PH>(s_lut, s_img, ty, x4, a.C, acc);
+    }
+    const int y = y0 + ty;
+    if (y < a.oy1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (c < a.C) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int x = x0 + x4 + i;
+                    if (x < a.W)
+                        *const_cast<uint8_t *>(view_addr(a.out, n, c, y, x)) = (uint8_t)rhe_clip_u8(acc[c * 4 + i] + a.bias_num, a.div);
+                }
+            }
+    }
+}
+
 constexpr int K1_TW = 64, K1_TH = 64, K1_NT = 1024, K1_SPT = 12;  // 3 ch * 64*64 / 1024 = 12
 static_assert(K1_SPT * K1_NT >= 3 * K1_TW * K1_TH, "SPT too small for 3 channels");
 
 void stage_u1_tile(int &tw, int &th) { tw = K1_TW; th = K1_TH; }
 const char *stage_u1_name() { return "stage_u1_kernel"; }
 
-hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st) {
+hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant) {
     if (a.C > 3) return hipErrorInvalidValue;
-    auto kern = stage_u1_kernel<K1_TW, K1_TH, K1_NT, K1_SPT>;
+    auto kern = variant == 1 ? stage_u1_kernel<K1_TW, K1_TH, K1_NT, K1_SPT> : stage_u1w_kernel<K1_TW, K1_TH, K1_NT>;
     const size_t lds = (size_t)kU1TableBytes + (size_t)a.C * (K1_TH + 2 * kHalo) * (K1_TW + 2 * kHalo);
-    static bool attr_set[64] = {};  // per device: >64 KB of dynamic LDS has to be opted into
+    static bool attr_set[64][2] = {};  // per device and variant: >64 KB of dynamic LDS has to be opted into
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev][variant == 1]) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev][variant == 1] = true;
     }
     const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;
     if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;

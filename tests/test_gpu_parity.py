@@ -343,6 +343,9 @@ def test_hybrid_final_stage_variants_agree_and_capture(eng, shipped_luts):
             eng.set_tuning("hybrid_oob_per_1024", thr)
         assert torch.equal(eng.pipeline(x), want), (sel, thr)
     eng.set_tuning("hybrid_oob_per_1024", 128).set_tuning("final_stage_kernel", 0)
+    eng.set_tuning("first_stage_kernel", 1)                 # first stage: one-read-per-neighbour kernel == window kernel
+    assert torch.equal(eng.pipeline(x), want)
+    eng.set_tuning("first_stage_kernel", 0)
     # capture the default path
     out = torch.empty_like(want)
     eng.reserve(3, 150, 200, 3)

@@ -55,8 +55,11 @@ def main():
     engines = {}
     for n in names:
         e = MuLUTEngine(0, lib_path=libs[n]).configure(2, "sdy", 4, 4).set_lut_dict(luts)
-        if "@" in n:
+        if "@" in n:                      # name@final[:threshold][/first]
             sel = n.split("@")[1]
+            if "/" in sel:
+                sel, fst = sel.split("/")
+                e.set_tuning("first_stage_kernel", int(fst))
             e.set_tuning("final_stage_kernel", int(sel.split(":")[0]))
             if ":" in sel:
                 e.set_tuning("hybrid_oob_per_1024", int(sel.split(":")[1]))

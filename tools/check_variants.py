@@ -17,10 +17,13 @@ for (h, w) in ((150, 200), (37, 129), (270, 480)):
     x = torch.from_numpy(fr).cuda()
     e.set_tuning("final_stage_kernel", 1)
     want = e.pipeline(x).clone()
-    for sel in (2, 3, 4):
-        e.set_tuning("final_stage_kernel", sel)
-        got = e.pipeline(x)
-        same = torch.equal(got, want)
-        ok &= same
-        print(h, w, "kernel", sel, "OK" if same else "MISMATCH %d" % int((got != want).sum()))
+    e.set_tuning("first_stage_kernel", 1)
+    want = e.pipeline(x).clone()
+    for first in (0, 1):
+        for sel in (2, 3, 4):
+            e.set_tuning("final_stage_kernel", sel).set_tuning("first_stage_kernel", first)
+            got = e.pipeline(x)
+            same = torch.equal(got, want)
+            ok &= same
+            print(h, w, "first", first, "final", sel, "OK" if same else "MISMATCH %d" % int((got != want).sum()))
 sys.exit(0 if ok else 1)
