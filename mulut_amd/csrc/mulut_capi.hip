@@ -478,7 +478,7 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
 
 const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (!ctx || !ctx->configured) return "";
-    if (!is_final || ctx->scale == 1) return stage_u1_name();
+    if (!is_final || ctx->scale == 1) return stage_u1_name(ctx->first_kernel);
     if (ctx->scale == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1)
         return ctx->final_kernel == 2 ? stage_band_name(kOutPackedRGBU4)
                : ctx->final_kernel == 3 ? stage_bandx_name(kOutPackedRGBU4)

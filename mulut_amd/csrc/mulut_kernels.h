@@ -81,7 +81,7 @@ void stage_band_tile(int &tw, int &th);
 const char *stage_band_name(int out_mode);
 void stage_u1_tile(int &tw, int &th);
 void stage_up_tile(int &tw, int &th);
-const char *stage_u1_name();
+const char *stage_u1_name(int variant);
 const char *stage_up_name(int u, int out_mode);
 
 }  // namespace mulut

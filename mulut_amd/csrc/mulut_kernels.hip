@@ -377,7 +377,7 @@ constexpr int K1_TW = 64, K1_TH = 64, K1_NT = 1024, K1_SPT = 12;  // 3 ch * 64*6
 static_assert(K1_SPT * K1_NT >= 3 * K1_TW * K1_TH, "SPT too small for 3 channels");
 
 void stage_u1_tile(int &tw, int &th) { tw = K1_TW; th = K1_TH; }
-const char *stage_u1_name() { return "stage_u1_kernel"; }
+const char *stage_u1_name(int variant) { return variant == 1 ? "stage_u1_kernel" : "stage_u1w_kernel"; }
 
 hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant) {
     if (a.C > 3) return hipErrorInvalidValue;
