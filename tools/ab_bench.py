@@ -22,6 +22,16 @@ from mulut_amd import MuLUTEngine, _native, load_lut_dict  # noqa: E402
 from mulut_amd.synth import natural_frames, noise_frames, real_frames  # noqa: E402
 
 
+COMPILER_VARIANTS = {
+    "ilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "mclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+    "itilp": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+    "itminreg": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
+    "nosched": ["-mllvm", "-enable-misched=0"],
+    "o2": ["-O2"],
+}
+
+
 def build_variant(name):
     name = name.split("@")[0]
     if name == "base":
@@ -30,10 +40,12 @@ def build_variant(name):
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libmulut_%s.so" % name)
     flag = "-DMULUT_ABLATE=%s" % name[1:] if name[0] == "a" and name[1:].isdigit() else "-DMULUT_VARIANT_%s=1" % name
+    if name in COMPILER_VARIANTS:        # same source, other compiler options
+        flag = COMPILER_VARIANTS[name]
     srcs = [os.path.join(_native._CSRC, f) for f in _native.SOURCES]
     newest = max(os.path.getmtime(os.path.join(_native._CSRC, f)) for f in _native.SOURCES + _native.HEADERS)
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
-        subprocess.check_call([_native._hipcc()] + _native.HIPCC_FLAGS + [flag, "-o", so] + srcs)
+        subprocess.check_call([_native._hipcc()] + _native.HIPCC_FLAGS + (flag if isinstance(flag, list) else [flag]) + ["-o", so] + srcs)
     return so
 
 
