@@ -108,6 +108,30 @@ __device__ __forceinline__ void load_tile(const StageArgs &a, int n, int y0, int
     }
 }
 
+// The same copy with every byte load of a thread in flight before the first LDS store: a workgroup that owns
+// the whole CU (K1) has nobody to hide a dependent load chain behind, so the chain must not exist.
+template <int TW, int TH, int NT>
+__device__ __forceinline__ void load_tile_batched(const StageArgs &a, int n, int y0, int x0, uint8_t *s_img) {
+    constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
+    constexpr int PER = (3 * PH * PW + NT - 1) / NT;
+    const int total = a.C * PH * PW;
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    uint8_t v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = (int)threadIdx.x + k * NT;
+        const int px = i % PW, py = (i / PW) % PH, c = imin(i / (PW * PH), a.C - 1);   // past the end: a valid address, never stored
+        const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
+        const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
+        v[k] = *view_addr(a.in, n, c, gy, gx);
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = (int)threadIdx.x + k * NT;
+        if (i < total) s_img[i] = v[k];
+    }
+}
+
 // same tile, stored as 16-bit pixel codes (mulut_core.h pixel_code) for the expanded-band kernel
 template <int TW, int TH, int NT>
 __device__ __forceinline__ void load_tile_code(const StageArgs &a, int n, int y0, int x0, uint16_t *s_img) {
@@ -337,7 +361,20 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
 
     int n, y0, x0;
     decode_tile(a, xcd_remap(blockIdx.x, gridDim.x), n, y0, x0, TW, TH);
-    load_tile<TW, TH, NT>(a, n, y0, x0, s_img);
+    // The table of the NEXT mode travels through registers: fetched (6 x 16 B per thread) while the current mode is
+    // being computed, written to LDS between the two barriers of the swap -- the swap then costs LDS stores only.
+    static_assert((kU1TableBytes / 16 + NT - 1) / NT == 6, "six 16-byte chunks of the table per thread");
+    constexpr int kVecs = kU1TableBytes / 16;
+    const int c0 = (int)threadIdx.x, c5 = c0 + 5 * NT < kVecs ? c0 + 5 * NT : 0;   // chunk 5 exists for the first threads only
+    uint4 n0, n1, n2, n3, n4, n5;   // named, not an array: they must live in registers across the mode body
+#define MULUT_U1_FETCH(LUT)                                                                                         \
+    do {                                                                                                            \
+        const uint4 *src_ = (const uint4 *)(LUT);                                                                   \
+        n0 = src_[c0]; n1 = src_[c0 + NT]; n2 = src_[c0 + 2 * NT]; n3 = src_[c0 + 3 * NT]; n4 = src_[c0 + 4 * NT];  \
+        n5 = src_[c5];                                                                                              \
+    } while (0)
+    MULUT_U1_FETCH(a.lut[0]);
+    load_tile_batched<TW, TH, NT>(a, n, y0, x0, s_img);
     const int x4 = (int)(threadIdx.x % (TW / 4)) * 4, ty = (int)(threadIdx.x / (TW / 4));
     int acc[12];   // [channel][pixel]
 #pragma unroll
@@ -345,13 +382,14 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
 
     for (int mv = 0; mv < a.M; ++mv) {
         const int m = __builtin_amdgcn_readfirstlane(mv);
-        __syncthreads();  // tile filled (m == 0) / everyone done with the previous table
+        __syncthreads();  // everyone done with the previous table
         {
-            const uint4 *src = (const uint4 *)a.lut[m];
             uint4 *dst = (uint4 *)smem;
-            for (int i = threadIdx.x; i < kU1TableBytes / 16; i += NT) dst[i] = src[i];
+            dst[c0] = n0; dst[c0 + NT] = n1; dst[c0 + 2 * NT] = n2; dst[c0 + 3 * NT] = n3; dst[c0 + 4 * NT] = n4;
+            if (c0 + 5 * NT < kVecs) dst[c0 + 5 * NT] = n5;
         }
-        __syncthreads();
+        if (mv + 1 < a.M) MULUT_U1_FETCH(a.lut[__builtin_amdgcn_readfirstlane(mv + 1)]);
+        __syncthreads();  // table and (m == 0) tile in place
         // pattern of this mode from its first key offset: s (0,1), d (0,2), y (1,1) -- scalar
         const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
         if (pat == 0) u1w_mode<0, PW, PH>(s_lut, s_img, ty, x4, a.C, acc);
@@ -371,6 +409,7 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
                 }
             }
     }
+#undef MULUT_U1_FETCH
 }
 
 constexpr int K1_TW = 64, K1_TH = 64, K1_NT = 1024, K1_SPT = 12;  // 3 ch * 64*64 / 1024 = 12
