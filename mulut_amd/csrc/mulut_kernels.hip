@@ -454,11 +454,22 @@ __global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *v
     if (threadIdx.x == 0) { s_cnt = 0; s_valid = 0; }
     const int total = a.C * PH * PW;
     const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int px = i % PW, py = (i / PW) % PH, c = i / (PW * PH);
-        const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
-        const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
-        s_h[i] = *view_addr(a.in, n, c, gy, gx) >> 4;
+    {   // every byte load of the thread in flight before the first LDS store (the kernel is nothing but latency)
+        constexpr int PER = (3 * PH * PW + 255) / 256;
+        uint8_t v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = (int)threadIdx.x + k * 256;
+            const int px = i % PW, py = (i / PW) % PH, c = imin(i / (PW * PH), a.C - 1);
+            const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
+            const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
+            v[k] = *view_addr(a.in, n, c, gy, gx);
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = (int)threadIdx.x + k * 256;
+            if (i < total) s_h[i] = v[k] >> 4;
+        }
     }
     __syncthreads();
     // a verdict is a heuristic: every second site in x and y is enough (4x less LDS work)
