@@ -18,6 +18,7 @@ struct DevTable {
     void *dev = nullptr;    // full table image
     void *band = nullptr;   // diagonal band image (v_num == 16 only), kBandRows x 16 B
     void *bandx = nullptr;  // the same rows expanded to 16-bit fields, kBandRows x 32 B
+    void *tube = nullptr;   // "tube" band (keys spanning <= 2 MSB steps) expanded to 16-bit fields, two planes of kTubeSlots x 16 B
     int vnum = 0;
     size_t bytes = 0;
 };
@@ -34,7 +35,8 @@ struct mulut_ctx {
     size_t ws_bytes = 0;
     std::string hip_err;
     int num_cus = 256;
-    int final_kernel = 0;   // 0 auto (= 4 hybrid), 1 full-table kernel, 2 compact LDS band, 3 expanded LDS band, 4 hybrid
+    int final_kernel = 0;   // 0 auto (= 4 hybrid), 1 full-table kernel, 2 compact LDS band, 3 expanded LDS band, 4 hybrid (band-x),
+                            // 5 tube kernel (all bands resident), 6 hybrid (tube)
     int f32_ok[2] = {0, 0}; // float epilogue proven exact for the [non-final, final] divisor
     uint32_t *verdict = nullptr;   // per-tile smooth/detailed verdicts of the hybrid final stage
     size_t verdict_tiles = 0;
@@ -107,6 +109,7 @@ int mulut_destroy(mulut_ctx *ctx) {
             if (t.dev) (void)hipFree(t.dev);
             if (t.band) (void)hipFree(t.band);
             if (t.bandx) (void)hipFree(t.bandx);
+            if (t.tube) (void)hipFree(t.tube);
         }
     for (auto &w : ctx->ws)
         if (w) (void)hipFree(w);
@@ -200,10 +203,27 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
             }
         if (!t.bandx) HIP_TRY(ctx, hipMalloc(&t.bandx, bx.size() * 4));
         HIP_TRY(ctx, hipMemcpy(t.bandx, bx.data(), bx.size() * 4, hipMemcpyHostToDevice));
+        // tube band: rows with max - min of the keys <= 2 at tube_slot(), same two-plane expansion
+        std::vector<uint32_t> tb((size_t)kTubeBandBytes / 4, 0x00800080u);
+        for (int A = 0; A < kL; ++A)
+            for (int B = imax(0, A - 2); B <= imin(kL - 1, A + 2); ++B)
+                for (int C = imax(0, A - 2); C <= imin(kL - 1, A + 2); ++C)
+                    for (int D = imax(0, A - 2); D <= imin(kL - 1, A + 2); ++D) {
+                        if (!tube_contains(A, B, C, D)) continue;
+                        const uint8_t *e = &img[((size_t)A * kStrideA + B * kStrideB + C * kStrideC + D) * 16];
+                        const size_t s4 = (size_t)tube_slot(A, B, C, D) * 4;
+                        for (int k = 0; k < 4; ++k) {
+                            tb[s4 + k] = (uint32_t)e[4 * k] | ((uint32_t)e[4 * k + 2] << 16);
+                            tb[(size_t)kTubePlaneBytes / 4 + s4 + k] = (uint32_t)e[4 * k + 1] | ((uint32_t)e[4 * k + 3] << 16);
+                        }
+                    }
+        if (!t.tube) HIP_TRY(ctx, hipMalloc(&t.tube, tb.size() * 4));
+        HIP_TRY(ctx, hipMemcpy(t.tube, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
     } else if (t.band) {
         HIP_TRY(ctx, hipFree(t.band));
         HIP_TRY(ctx, hipFree(t.bandx));
-        t.band = t.bandx = nullptr;
+        HIP_TRY(ctx, hipFree(t.tube));
+        t.band = t.bandx = t.tube = nullptr;
     }
     return MULUT_OK;
 }
@@ -287,7 +307,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.inv_d = 1.0f / (float)a.div.d;
     a.use_f32 = ctx->f32_ok[last ? 1 : 0];
     const bool band = u == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1;
-    const bool hybrid = band && (ctx->final_kernel == 0 || ctx->final_kernel == 4);
+    const bool hybrid = band && (ctx->final_kernel == 0 || ctx->final_kernel == 4 || ctx->final_kernel == 6);
+    const bool tube = ctx->final_kernel == 5 || ctx->final_kernel == 6;
     a.verdict = nullptr;
     a.verdict_take = -1;
     int tw, th;
@@ -309,7 +330,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     BandArgs b;
     for (int m = 0; m < ctx->n_modes; ++m) {
         const DevTable &t = ctx->tab[stage - 1][pattern_id(ctx->modes[m])];
-        b.band[m] = x ? t.bandx : t.band;
+        b.band[m] = tube ? t.tube : x ? t.bandx : t.band;
     }
     if (hybrid) {
         // per-tile choice on the device: smooth tiles -> LDS band kernel, detailed tiles -> full-table kernel
@@ -320,7 +341,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.vt_x = a.tiles_x;
         a.vt_y = a.tiles_y;
         a.verdict_take = 0;
-        HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
+        if (tube) HIP_TRY(ctx, launch_stage_tube(a, b, mode, ctx->num_cus, st));
+        else HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
         StageArgs g = a;
         int gw, gh;
         stage_up_tile(gw, gh);
@@ -330,7 +352,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         HIP_TRY(ctx, launch_stage_up(g, u, mode, st));
         return MULUT_OK;
     }
-    if (x) HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
+    if (tube) HIP_TRY(ctx, launch_stage_tube(a, b, mode, ctx->num_cus, st));
+    else if (x) HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
     else HIP_TRY(ctx, launch_stage_band(a, b, mode, ctx->num_cus, st));
     return MULUT_OK;
 }
@@ -459,7 +482,7 @@ int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap) {
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return MULUT_EINVAL;
     if (!strcmp(key, "final_stage_kernel")) {
-        if (value < 0 || value > 4) return MULUT_EINVAL;
+        if (value < 0 || value > 6) return MULUT_EINVAL;
         ctx->final_kernel = value;
         return MULUT_OK;
     }

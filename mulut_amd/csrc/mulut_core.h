@@ -347,6 +347,69 @@ MULUT_HD void simplex4_band_pair_code(uint32_t ca, uint32_t pb, uint32_t pc, uin
     o.t_band = pk_sub_sat(t, pk_dup(32u));
 }
 
+// ---- "tube" band: rows whose four keys span at most two MSB steps -----------------------------------------
+// A pass whose four MSBs satisfy max - min <= 1 touches only rows with max - min <= 2.  There are 991 such
+// rows in the 17^4 table, and the affine map
+//      slot = 27 A + 18 B + 12 C + 8 D                      (27 + 18 + 12 + 8 = 65)
+// is injective on them with range 0..1040 (found by exhaustive search; checked in tests/host_emul): 1041
+// 16-byte slots per plane, so the bands of all three modes, expanded to 16-bit fields (two planes each),
+// fit LDS together (3 x 33,312 B) and no band is ever swapped.  The strides are 11, 2, 12, 8 mod 16: any two
+// rows whose keys differ by at most one step per key land in different 16-byte bank groups of a
+// ds_read_b128 lane group (|11a + 2b + 12c + 8d| mod 16 != 0 for a,b,c,d in {-1,0,1} not all zero).
+constexpr int kTubeSA = 27, kTubeSB = 18, kTubeSC = 12, kTubeSD = 8;
+constexpr int kTubeAll = kTubeSA + kTubeSB + kTubeSC + kTubeSD;       // 65: slot(p1111) - slot(p0000)
+constexpr int kTubeSlots = (kL - 1) * kTubeAll + 1;                    // 1041
+constexpr int kTubePlaneBytes = kTubeSlots * 16;                       // 16656
+constexpr int kTubeBandBytes = 2 * kTubePlaneBytes;                    // 33312: LO plane, HI plane
+MULUT_HD constexpr bool tube_contains(int A, int B, int C, int D) {
+    const int mx = A > B ? (A > C ? (A > D ? A : D) : (C > D ? C : D)) : (B > C ? (B > D ? B : D) : (C > D ? C : D));
+    const int mn = A < B ? (A < C ? (A < D ? A : D) : (C < D ? C : D)) : (B < C ? (B < D ? B : D) : (C < D ? C : D));
+    return mx - mn <= 2;
+}
+MULUT_HD constexpr int tube_slot(int A, int B, int C, int D) { return A * kTubeSA + B * kTubeSB + C * kTubeSC + D * kTubeSD; }
+
+// Two passes (low half = pass A, high half = pass B) of one site against a tube band, on pixel codes
+// (pixel_code below): ca = anchor code in the low half, pb/pc/pd = packed code pairs.  `bias` (a multiple of
+// 16, duplicated into both halves by the caller's constant) is added to every row offset so that the caller
+// can keep the plane's LDS address within the 16-bit immediate of ds_read.  t_oob is zero in a half iff that
+// pass is in the tube (max - min of its four MSBs <= 1).
+struct TubePair {
+    uint32_t addr[5];   // byte offsets of the five rows inside a plane (+ bias), packed per pass
+    uint32_t w[5];      // weights, packed per pass
+    uint32_t t_oob;
+};
+MULUT_HD void simplex4_tube_pair(uint32_t ca, uint32_t pb, uint32_t pc, uint32_t pd, uint32_t bias_pk, TubePair &o) {
+    constexpr uint32_t SA = kTubeSA * 16, SB = kTubeSB * 16, SC = kTubeSC * 16, SD = kTubeSD * 16;   // byte strides < 4096
+    const uint32_t ha16 = pk_dup(ca & 0xF0u);
+    const uint32_t hb16 = pb & 0x00F000F0u, hc16 = pc & 0x00F000F0u, hd16 = pd & 0x00F000F0u;     // 16*h per half
+    uint32_t k0 = pk_dup((ca & 0xF000u) | SA);
+    uint32_t k1 = (pb & 0xF000F000u) | pk_dup(SB);
+    uint32_t k2 = (pc & 0xF000F000u) | pk_dup(SC);
+    uint32_t k3 = (pd & 0xF000F000u) | pk_dup(SD);
+    pk_cmpx_desc(k0, k1);
+    pk_cmpx_desc(k2, k3);
+    pk_cmpx_desc(k0, k2);
+    pk_cmpx_desc(k1, k3);
+    pk_cmpx_desc(k1, k2);
+    const uint32_t f1 = pk_shr12(k0), f2 = pk_shr12(k1), f3 = pk_shr12(k2), f4 = pk_shr12(k3);
+    // row offset in bytes = 16 * slot = (16 h) * slot stride, summed over the four keys
+    const uint32_t base = pk_mad(ha16, pk_dup(kTubeSA), pk_mad(hb16, pk_dup(kTubeSB), pk_mad(hc16, pk_dup(kTubeSC),
+                          pk_mad(hd16, pk_dup(kTubeSD), bias_pk))));
+    o.addr[0] = base;
+    o.addr[1] = pk_add(base, k0 & 0x0FFF0FFFu);
+    o.addr[2] = pk_add(o.addr[1], k1 & 0x0FFF0FFFu);
+    o.addr[3] = pk_add(o.addr[2], k2 & 0x0FFF0FFFu);
+    o.addr[4] = pk_add(base, pk_dup(kTubeAll * 16));
+    o.w[0] = pk_sub(pk_dup(kQ), f1);
+    o.w[1] = pk_sub(f1, f2);
+    o.w[2] = pk_sub(f2, f3);
+    o.w[3] = pk_sub(f3, f4);
+    o.w[4] = f4;
+    const uint32_t mx = pk_max(pk_max(hb16, hc16), pk_max(hd16, ha16));
+    const uint32_t mn = pk_min(pk_min(hb16, hc16), pk_min(hd16, ha16));
+    o.t_oob = pk_sub(mx, mn) & 0xFFE0FFE0u;     // differences are multiples of 16: in the tube iff 0 or 16
+}
+
 // ---- merged rotation pairs ----------------------------------------------------------------------------
 // Rotation r+2 maps row element e to the block position that rotation r gives element 15-e
 // (row_elem(r+2,sy,sx,4) == 15 - row_elem(r,sy,sx,4)), so the rows of rotation r+2 can be added

@@ -75,6 +75,10 @@ hipError_t launch_stage_band(const StageArgs &a, const BandArgs &b, int out_mode
 // same, with the band rows expanded to 16-bit fields in LDS (one mode resident, mode loop outermost)
 hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 const char *stage_bandx_name(int out_mode);
+// same, with the "tube" bands (mulut_core.h) of all modes resident together: b.band[m] = expanded tube image of
+// mode m (LO plane then HI plane, kTubeBandBytes); no band swaps, channel-outer loops
+hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
+const char *stage_tube_name(int out_mode);
 // per-tile smooth/detailed verdict for the hybrid final stage (tiles of stage_band_tile())
 hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st);
 void stage_band_tile(int &tw, int &th);

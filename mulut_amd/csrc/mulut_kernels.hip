@@ -1297,4 +1297,234 @@ hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mod
     return launch_bandx_t<kOutGeneric>(a, b, num_cus, st);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// K2-tube: final stage (u == 4, M <= 3) with the bands of ALL modes resident in LDS.
+// The band is the "tube" of mulut_core.h (rows whose keys span <= 2 MSB steps: 1041 slots), expanded to
+// 16-bit fields in two planes: 33,312 B per mode, 99,936 B for s, d and y together, so nothing is swapped
+// and a tile needs no barrier except the one that publishes the next image tile.  With every band at hand
+// the loops nest channel -> mode -> rotation pair: 16 accumulator VGPRs are live instead of 48, which
+// leaves room for all ten row reads of a pass in flight and for a general path that does not spill.
+// The pattern of a mode is a template parameter behind a scalar switch: every neighbour read is a
+// ds_read_u16 with an immediate offset from one per-channel window address.
+// LDS: [ band s | band d | band y : 33,312 B each ][ image tile 0 ][ image tile 1 ]  (pixel codes, 10,080 B each)
+// ------------------------------------------------------------------------------------------
+constexpr int kTubeTileBytes = ((2 * 3 * (16 + 2 * kHalo) * (64 + 2 * kHalo) + 15) / 16) * 16;
+constexpr int kTubeLdsBytes = 3 * kTubeBandBytes + 2 * kTubeTileBytes;
+// the packed row offsets carry this bias so that (plane address - bias) fits ds_read's 16-bit immediate
+__host__ __device__ constexpr int tube_bias(int pat) { return pat == 2 ? 32768 : 0; }
+
+// acc += x * w[WHALF] per 16-bit lane; SWAP exchanges the halves of x (reversed rotation).  One
+// v_pk_mad_u16 each, the selects are free (op_sel / op_sel_hi).
+template <int WHALF, bool SWAP>
+__device__ __forceinline__ void pk_mac(uint32_t &acc, uint32_t x, uint32_t wpk) {
+    if constexpr (WHALF == 0 && !SWAP) asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(wpk));
+    if constexpr (WHALF == 1 && !SWAP) asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(wpk));
+    if constexpr (WHALF == 0 && SWAP) asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(x), "v"(wpk));
+    if constexpr (WHALF == 1 && SWAP) asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(wpk));
+}
+
+// one row (LO + HI plane dwords) into the accumulators of rotation R, weight half HALF
+template <int R, int HALF>
+__device__ __forceinline__ void tube_mac_row(RotAcc<4> &acc, const uint4 &lo, const uint4 &hi, uint32_t wpk) {
+    const uint32_t rlo[4] = {lo.x, lo.y, lo.z, lo.w}, rhi[4] = {hi.x, hi.y, hi.z, hi.w};
+    static_for<0, 4>([&](auto K) {
+        constexpr int k = K;
+        if constexpr (R == 0) { pk_mac<HALF, false>(acc.lo02[k], rlo[k], wpk); pk_mac<HALF, false>(acc.hi02[k], rhi[k], wpk); }
+        if constexpr (R == 1) { pk_mac<HALF, false>(acc.lo13[k], rlo[k], wpk); pk_mac<HALF, false>(acc.hi13[k], rhi[k], wpk); }
+        if constexpr (R == 2) { pk_mac<HALF, true>(acc.lo02[3 - k], rhi[k], wpk); pk_mac<HALF, true>(acc.hi02[3 - k], rlo[k], wpk); }
+        if constexpr (R == 3) { pk_mac<HALF, true>(acc.lo13[3 - k], rhi[k], wpk); pk_mac<HALF, true>(acc.hi13[3 - k], rlo[k], wpk); }
+    });
+}
+
+// the five rows of one pass: all ten reads issued, then accumulated in order
+template <int R, int HALF, int IMM>
+__device__ __forceinline__ void tube_rows(const uint8_t *smem, const TubePair &bp, RotAcc<4> &acc) {
+    uint4 lo[5], hi[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint32_t off = HALF ? (bp.addr[j] >> 16) : (bp.addr[j] & 0xFFFFu);
+        lo[j] = *(const uint4 *)(smem + off + IMM);
+        hi[j] = *(const uint4 *)(smem + off + (IMM + kTubePlaneBytes));
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) tube_mac_row<R, HALF>(acc, lo[j], hi[j], bp.w[j]);
+}
+
+// rotations R and R + 2 of one site and mode.  win = LDS byte address of the site's 5x5 window corner.
+template <int PAT, int R, int PW>
+__device__ __forceinline__ void tube_pair(const StageArgs &a, const uint8_t *smem, uint32_t win, uint32_t ca, const void *lut, RotAcc<4> &acc) {
+    constexpr int IMM = PAT * kTubeBandBytes - tube_bias(PAT);
+    static_assert(IMM >= 0 && IMM + kTubePlaneBytes <= 65535 && tube_bias(PAT) + kTubePlaneBytes <= 65536, "ds_read immediate / packed offset range");
+    const uint16_t *w = (const uint16_t *)(smem + win);
+    constexpr int yb = rot_dy(R, kPatDi[PAT][0], kPatDj[PAT][0]), xb = rot_dx(R, kPatDi[PAT][0], kPatDj[PAT][0]);
+    constexpr int yc = rot_dy(R, kPatDi[PAT][1], kPatDj[PAT][1]), xc = rot_dx(R, kPatDi[PAT][1], kPatDj[PAT][1]);
+    constexpr int yd = rot_dy(R, kPatDi[PAT][2], kPatDj[PAT][2]), xd = rot_dx(R, kPatDi[PAT][2], kPatDj[PAT][2]);
+    // rotation R + 2 samples the opposite offsets
+    const uint32_t pb = w[(2 + yb) * PW + 2 + xb] | ((uint32_t)w[(2 - yb) * PW + 2 - xb] << 16);
+    const uint32_t pc = w[(2 + yc) * PW + 2 + xc] | ((uint32_t)w[(2 - yc) * PW + 2 - xc] << 16);
+    const uint32_t pd = w[(2 + yd) * PW + 2 + xd] | ((uint32_t)w[(2 - yd) * PW + 2 - xd] << 16);
+    TubePair bp;
+    simplex4_tube_pair(ca, pb, pc, pd, pk_dup((uint32_t)tube_bias(PAT)), bp);
+    if (!__all(bp.t_oob == 0u)) {
+        // rare: some lane has a pass outside the tube.  Those passes take their rows from the full table in
+        // global memory here, and their weights are zeroed so that the common row walk below adds nothing for
+        // them (any key combination still maps to a slot inside the band, so its reads stay in range).
+        const int va = pixel_value(ca);
+        uint32_t keep = 0xFFFFFFFFu;
+        if ((bp.t_oob & 0xFFFFu) != 0u) {
+            pass_global<4, R>(lut, va, pixel_value(pb & 0xFFFFu), pixel_value(pc & 0xFFFFu), pixel_value(pd & 0xFFFFu), a, acc);
+            keep &= 0xFFFF0000u;
+        }
+        if ((bp.t_oob >> 16) != 0u) {
+            pass_global<4, R + 2>(lut, va, pixel_value(pb >> 16), pixel_value(pc >> 16), pixel_value(pd >> 16), a, acc);
+            keep &= 0x0000FFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) bp.w[j] &= keep;
+    }
+    tube_rows<R, 0, IMM>(smem, bp, acc);
+    tube_rows<R + 2, 1, IMM>(smem, bp, acc);
+}
+
+template <int PAT, int PW>
+__device__ __forceinline__ void tube_mode(const StageArgs &a, const uint8_t *smem, uint32_t win, uint32_t ca, const void *lut, RotAcc<4> &acc) {
+    tube_pair<PAT, 0, PW>(a, smem, win, ca, lut, acc);
+    tube_pair<PAT, 1, PW>(a, smem, win, ca, lut, acc);
+}
+
+template <int OUT, int TW, int TH>
+__global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArgs b) {
+    constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
+    constexpr int NT = TW * TH;
+    constexpr int PER = (3 * PH * PW + NT - 1) / NT;          // image bytes per thread and tile
+    static_assert(((2 * 3 * PH * PW + 15) / 16) * 16 == kTubeTileBytes, "tile buffer size");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    const int G = gridDim.x;
+    const bool by_xcd = (G & 7) == 0;
+    const int per = (ntiles + 7) >> 3;
+    const int first = by_xcd ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int last = by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, ntiles) : ntiles;
+    const int step = by_xcd ? (G >> 3) : G;
+    // next tile of this workgroup at or after t that the verdict (if any) assigns to this kernel
+    auto next_tile = [&](int t) {
+        if (a.verdict_take >= 0)
+            while (t < last && (int)a.verdict[t] != a.verdict_take) t += step;
+        return t;
+    };
+    const int total = a.C * PH * PW;
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    // image bytes of a tile: all loads of a thread in flight together; they are stored (as pixel codes) later
+    auto fetch = [&](int tile, uint8_t (&v)[PER]) {
+        int n, y0, x0;
+        decode_tile(a, tile, n, y0, x0, TW, TH);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = (int)threadIdx.x + k * NT;
+            const int px = i % PW, py = (i / PW) % PH, c = imin(i / (PW * PH), a.C - 1);
+            const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
+            const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
+            v[k] = *view_addr(a.in, n, c, gy, gx);
+        }
+    };
+    auto stash = [&](int buf, const uint8_t (&v)[PER]) {
+        uint16_t *dst = (uint16_t *)(smem + 3 * kTubeBandBytes + buf * kTubeTileBytes);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = (int)threadIdx.x + k * NT;
+            if (i < total) dst[i] = (uint16_t)pixel_code(v[k]);
+        }
+    };
+
+    int tile = next_tile(first);
+    if (tile >= last) return;              // workgroup-uniform
+    uint8_t pix[PER];
+    fetch(tile, pix);
+    // bands: slot = pattern id of the mode (s, d, y); absent patterns are never read
+    for (int m = 0; m < a.M; ++m) {
+        const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
+        const uint4 *src = (const uint4 *)b.band[m];
+        uint4 *dst = (uint4 *)(smem + pat * kTubeBandBytes);
+        for (int i = threadIdx.x; i < kTubeBandBytes / 16; i += NT) dst[i] = src[i];
+    }
+    stash(0, pix);
+    __syncthreads();
+
+    for (int it = 0; tile < last; ++it) {
+        const int nxt = next_tile(tile + step);
+        if (nxt < last) fetch(nxt, pix);
+        int n, y0, x0;
+        decode_tile(a, tile, n, y0, x0, TW, TH);
+        const int y = y0 + ty, x = x0 + tx;
+        if (y < a.oy1 && x < a.W) {
+            // LDS byte address of the 5x5 window corner of this site, channel 0
+            uint32_t win = (uint32_t)(3 * kTubeBandBytes + (it & 1) * kTubeTileBytes + 2 * (ty * PW + tx));
+            uint32_t o0[4], o1[4], o2[4];     // packed output rows of the finished channels (RGB path)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o0[k] = o1[k] = o2[k] = 0;
+#pragma clang loop unroll(disable)
+            for (int c = 0; c < a.C; ++c, win += 2 * PH * PW) {
+                const uint32_t ca = *(const uint16_t *)(smem + win + 2 * (2 * PW + 2));
+                RotAcc<4> acc;
+                acc.clear();
+                for (int mv = 0; mv < a.M; ++mv) {
+                    const int m = __builtin_amdgcn_readfirstlane(mv);
+                    const void *lut = a.lut[m];
+                    const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;     // scalar
+                    if (pat == 0) tube_mode<0, PW>(a, smem, win, ca, lut, acc);
+                    else if (pat == 1) tube_mode<1, PW>(a, smem, win, ca, lut, acc);
+                    else tube_mode<2, PW>(a, smem, win, ca, lut, acc);
+                }
+                if constexpr (OUT == kOutPackedRGBU4) {
+                    acc.finalize();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { o0[k] = o1[k]; o1[k] = o2[k]; }
+                    o2[0] = finish_row4<0>(a, acc); o2[1] = finish_row4<1>(a, acc);
+                    o2[2] = finish_row4<2>(a, acc); o2[3] = finish_row4<3>(a, acc);
+                } else {
+                    uint32_t o[4];
+                    finish_channel<4, OUT>(a, acc, n, c, y, x, o);
+                }
+            }
+            if constexpr (OUT == kOutPackedRGBU4) store_rgb<4>(a, n, y, x, o0, o1, o2);
+        }
+        if (nxt < last) stash((it + 1) & 1, pix);
+        __syncthreads();     // next tile published; everyone is done reading the current one
+        tile = nxt;
+    }
+}
+
+const char *stage_tube_name(int out_mode) {
+    return out_mode == kOutPackedRGBU4 ? "stage_tube_kernel<rgb>" : out_mode == kOutPlanarU4 ? "stage_tube_kernel<planar>"
+                                                                                              : "stage_tube_kernel<generic>";
+}
+
+template <int OUT>
+static hipError_t launch_tube_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
+    auto kern = stage_tube_kernel<OUT, KB_TW, KB_TH>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
+    if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(ntiles < num_cus ? ntiles : num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(KB_TW * KB_TH), (size_t)kTubeLdsBytes, st, a, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st) {
+    if (a.C > 3 || a.M > 3) return hipErrorInvalidValue;
+    if (out_mode == kOutPlanarU4) return launch_tube_t<kOutPlanarU4>(a, b, num_cus, st);
+    if (out_mode == kOutPackedRGBU4 && a.C == 3) return launch_tube_t<kOutPackedRGBU4>(a, b, num_cus, st);
+    return launch_tube_t<kOutGeneric>(a, b, num_cus, st);
+}
+
 }  // namespace mulut

@@ -337,7 +337,7 @@ def test_hybrid_final_stage_variants_agree_and_capture(eng, shipped_luts):
     eng.set_tuning("final_stage_kernel", 1)
     want = eng.pipeline(x).clone()
     assert np.array_equal(want[2].cpu().numpy(), c_oracle.pipeline(shipped_luts, 2, "sdy", 4, frames[2]))
-    for sel, thr in ((2, None), (3, None), (4, 0), (4, 128), (4, 1024), (0, None)):
+    for sel, thr in ((2, None), (3, None), (4, 0), (4, 128), (4, 1024), (5, None), (6, 0), (6, 128), (6, 1024), (0, None)):
         eng.set_tuning("final_stage_kernel", sel)
         if thr is not None:
             eng.set_tuning("hybrid_oob_per_1024", thr)

@@ -63,7 +63,7 @@ def main():
                 else:
                     luts["s%d_%s" % (s + 1, m)] = synthetic_lut(int(rng.integers(1 << 30)), vn)
         e = MuLUTEngine(0).configure(stages, modes, scale, 4).set_lut_dict(luts)
-        e.set_tuning("final_stage_kernel", int(rng.integers(0, 5)))
+        e.set_tuning("final_stage_kernel", int(rng.integers(0, 7)))
         e.set_tuning("hybrid_oob_per_1024", int(rng.choice([0, 16, 128, 512, 1024])))
         e.set_tuning("first_stage_kernel", int(rng.integers(0, 2)))
         n = int(rng.integers(1, 4))
