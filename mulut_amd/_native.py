@@ -43,10 +43,16 @@ def build(force=False, verbose=False):
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libmulut_hip.so (no CPU fallback exists)")
     os.makedirs(_LIBDIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + SOURCES
+    tmp = "%s.%d.tmp" % (LIB_PATH, os.getpid())     # never expose a half-written library to another rank
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + SOURCES
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=_CSRC)
+    try:
+        subprocess.check_call(cmd, cwd=_CSRC)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 
@@ -57,7 +63,11 @@ def load(path=None):
     if path in _libs:
         return _libs[path]
     if path == LIB_PATH and needs_build():
-        if _hipcc() is not None:
+        if os.environ.get("MULUT_NO_BUILD") == "1":
+            # profiler runs (the preloaded tool has initialised the GPU) and non-zero ranks must never compile
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError("libmulut_hip.so is missing and MULUT_NO_BUILD=1 forbids building it here")
+        elif _hipcc() is not None:
             build()
         elif not os.path.exists(LIB_PATH):
             raise RuntimeError("libmulut_hip.so is missing and hipcc is unavailable; "

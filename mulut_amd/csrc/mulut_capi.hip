@@ -35,9 +35,11 @@ struct mulut_ctx {
     size_t ws_bytes = 0;
     std::string hip_err;
     int num_cus = 256;
-    int final_kernel = 0;   // 0 auto (= 4 hybrid), 1 full-table kernel, 2 compact LDS band, 3 expanded LDS band, 4 hybrid (band-x),
+    int final_kernel = 0;   // 0 auto (= 6 hybrid with the tube kernel), 1 full-table kernel, 2 compact LDS band, 3 expanded LDS band, 4 hybrid (band-x),
                             // 5 tube kernel (all bands resident), 6 hybrid (tube)
     int f32_ok[2] = {0, 0}; // float epilogue proven exact for the [non-final, final] divisor
+    int fma_ok = 0;         // fused (biased-sum) float epilogue proven exact for the final stage
+    float epi_c = 0.0f;
     uint32_t *verdict = nullptr;   // per-tile smooth/detailed verdicts of the hybrid final stage
     size_t verdict_tiles = 0;
     int first_kernel = 0;   // 1-byte-row stages: 0 window kernel, 1 the original one-site-per-read kernel
@@ -145,6 +147,13 @@ int mulut_configure(mulut_ctx *ctx, int stages, const char *modes, int scale, in
         const int span = 128 * kQ * 4 * (int)M;      // |q * sum| <= 128 * 16 * 4M
         ctx->f32_ok[last] = rhe_f32_valid(-span + stage_bias_num((int)M, last != 0), span + stage_bias_num((int)M, last != 0),
                                           dm, 1.0f / (float)dm.d) ? 1 : 0;
+    }
+    {   // final stage on value+128 rows: sums are biased by 128 per weight unit, S in [0, 255 * 16 * 4M]
+        const DivMagic dm = make_div_magic((uint32_t)stage_divisor((int)M, true));
+        const int unbias = 128 * kQ * 4 * (int)M - stage_bias_num((int)M, true);
+        const float inv_d = 1.0f / (float)dm.d;
+        ctx->epi_c = -(float)unbias * inv_d;
+        ctx->fma_ok = rhe_fma_valid((uint32_t)(255 * kQ * 4 * (int)M), unbias, dm, inv_d, ctx->epi_c) ? 1 : 0;
     }
     ctx->configured = true;
     return MULUT_OK;
@@ -306,9 +315,11 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.bias_num = stage_bias_num(ctx->n_modes, last);
     a.inv_d = 1.0f / (float)a.div.d;
     a.use_f32 = ctx->f32_ok[last ? 1 : 0];
+    a.epi_c = ctx->epi_c;
+    a.use_fma = last ? ctx->fma_ok : 0;
     const bool band = u == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1;
     const bool hybrid = band && (ctx->final_kernel == 0 || ctx->final_kernel == 4 || ctx->final_kernel == 6);
-    const bool tube = ctx->final_kernel == 5 || ctx->final_kernel == 6;
+    const bool tube = ctx->final_kernel == 0 || ctx->final_kernel == 5 || ctx->final_kernel == 6;
     a.verdict = nullptr;
     a.verdict_take = -1;
     int tw, th;
@@ -505,6 +516,8 @@ const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (ctx->scale == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1)
         return ctx->final_kernel == 2 ? stage_band_name(kOutPackedRGBU4)
                : ctx->final_kernel == 3 ? stage_bandx_name(kOutPackedRGBU4)
+               : ctx->final_kernel == 5 ? stage_tube_name(kOutPackedRGBU4)
+               : (ctx->final_kernel == 6 || ctx->final_kernel == 0) ? "hybrid: tile_stat_kernel + stage_tube_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)"
                                         : "hybrid: tile_stat_kernel + stage_bandx_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)";
     return stage_up_name(ctx->scale, ctx->scale == 4 ? kOutPackedRGBU4 : kOutGeneric);
 }

@@ -154,9 +154,19 @@ MULUT_HD uint32_t swar_field(const uint32_t (&lo)[RW], const uint32_t (&hi)[RW])
 
 // [r0 r1 r2 r3],[g0..g3],[b0..b3] -> r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3 (12 bytes of one HR row)
 MULUT_HD void interleave_rgb4(uint32_t R, uint32_t G, uint32_t B, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // two v_perm_b32 per output dword (selector bytes 0-3 pick from the second operand, 4-7 from the first)
+    const uint32_t rg0 = __builtin_amdgcn_perm(G, R, 0x01000400u);   // r0 g0 -- r1
+    const uint32_t gr1 = __builtin_amdgcn_perm(R, G, 0x02060001u);   // g1 -- r2 g2   (G = second operand)
+    const uint32_t rg2 = __builtin_amdgcn_perm(G, R, 0x00070300u);   // -- r3 g3 --
+    w0 = __builtin_amdgcn_perm(B, rg0, 0x03040100u);                 // r0 g0 b0 r1
+    w1 = __builtin_amdgcn_perm(B, gr1, 0x03020500u);                 // g1 b1 r2 g2
+    w2 = __builtin_amdgcn_perm(B, rg2, 0x07020106u);                 // b2 r3 g3 b3
+#else
     w0 = (R & 0xFFu) | ((G & 0xFFu) << 8) | ((B & 0xFFu) << 16) | ((R & 0xFF00u) << 16);
     w1 = ((G >> 8) & 0xFFu) | (B & 0xFF00u) | (R & 0xFF0000u) | ((G & 0xFF0000u) << 8);
     w2 = ((B >> 16) & 0xFFu) | ((R >> 16) & 0xFF00u) | ((G >> 8) & 0xFF0000u) | (B & 0xFF000000u);
+#endif
 }
 
 // compile-time loop: the body receives an IC<I>, so every register-array index is a constant
@@ -395,19 +405,21 @@ MULUT_HD void simplex4_tube_pair(uint32_t ca, uint32_t pb, uint32_t pc, uint32_t
     // row offset in bytes = 16 * slot = (16 h) * slot stride, summed over the four keys
     const uint32_t base = pk_mad(ha16, pk_dup(kTubeSA), pk_mad(hb16, pk_dup(kTubeSB), pk_mad(hc16, pk_dup(kTubeSC),
                           pk_mad(hd16, pk_dup(kTubeSD), bias_pk))));
+    // plain 32-bit adds / subtracts from here on (full-rate VALU ops; the packed forms are half rate): no half
+    // ever carries or borrows -- offsets stay below 2^16, the sorted f's are descending, max >= min
     o.addr[0] = base;
-    o.addr[1] = pk_add(base, k0 & 0x0FFF0FFFu);
-    o.addr[2] = pk_add(o.addr[1], k1 & 0x0FFF0FFFu);
-    o.addr[3] = pk_add(o.addr[2], k2 & 0x0FFF0FFFu);
-    o.addr[4] = pk_add(base, pk_dup(kTubeAll * 16));
-    o.w[0] = pk_sub(pk_dup(kQ), f1);
-    o.w[1] = pk_sub(f1, f2);
-    o.w[2] = pk_sub(f2, f3);
-    o.w[3] = pk_sub(f3, f4);
+    o.addr[1] = base + (k0 & 0x0FFF0FFFu);
+    o.addr[2] = o.addr[1] + (k1 & 0x0FFF0FFFu);
+    o.addr[3] = o.addr[2] + (k2 & 0x0FFF0FFFu);
+    o.addr[4] = base + pk_dup(kTubeAll * 16);     // (the kernels read row 4 through addr[0] and an immediate)
+    o.w[0] = pk_dup(kQ) - f1;
+    o.w[1] = f1 - f2;
+    o.w[2] = f2 - f3;
+    o.w[3] = f3 - f4;
     o.w[4] = f4;
     const uint32_t mx = pk_max(pk_max(hb16, hc16), pk_max(hd16, ha16));
     const uint32_t mn = pk_min(pk_min(hb16, hc16), pk_min(hd16, ha16));
-    o.t_oob = pk_sub(mx, mn) & 0xFFE0FFE0u;     // differences are multiples of 16: in the tube iff 0 or 16
+    o.t_oob = (mx - mn) & 0xFFE0FFE0u;     // differences are multiples of 16: in the tube iff 0 or 16
 }
 
 // ---- merged rotation pairs ----------------------------------------------------------------------------
@@ -518,6 +530,37 @@ MULUT_HD uint32_t rhe_pack4_f32(int K0, int K1, int K2, int K3, float inv_d) {
     return rhe_clip_u8_f32(K0, inv_d) | (rhe_clip_u8_f32(K1, inv_d) << 8) | (rhe_clip_u8_f32(K2, inv_d) << 16) |
            (rhe_clip_u8_f32(K3, inv_d) << 24);
 #endif
+}
+
+// Fused form for biased sums: clip(rhe((S - unbias) / d)) as  cvt -> fma(S, fl(1/d), c) -> rndne -> saturating u8
+// convert, with c = fl(-unbias * fl(1/d)): the subtraction rides in the fma.  Exactness is again proven by brute
+// force over every reachable sum at configure time (rhe_fma_valid).
+MULUT_HD uint32_t rhe_clip_u8_fma(uint32_t S, float inv_d, float c) {
+    const float q = __builtin_rintf(__builtin_fmaf((float)S, inv_d, c));
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_cvt_pk_u8_f32(q, 0u, 0u);
+#else
+    return q < 0.0f ? 0u : (q > 255.0f ? 255u : (uint32_t)q);
+#endif
+}
+MULUT_HD uint32_t rhe_pack4_fma(uint32_t S0, uint32_t S1, uint32_t S2, uint32_t S3, float inv_d, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_cvt_pk_u8_f32 itself rounds to nearest even and saturates to 0..255 (measured on gfx950 over -8..504 in steps
+    // of 1/128, tools/probe_cvt.hip: 0 differences from rintf + clamp), so no v_rndne_f32 is needed in front of it
+    uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)S0, inv_d, c), 0u, 0u);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)S1, inv_d, c), 1u, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)S2, inv_d, c), 2u, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)S3, inv_d, c), 3u, r);
+    return r;
+#else
+    return rhe_clip_u8_fma(S0, inv_d, c) | (rhe_clip_u8_fma(S1, inv_d, c) << 8) | (rhe_clip_u8_fma(S2, inv_d, c) << 16) |
+           (rhe_clip_u8_fma(S3, inv_d, c) << 24);
+#endif
+}
+MULUT_HD bool rhe_fma_valid(uint32_t smax, int unbias, DivMagic m, float inv_d, float c) {
+    for (uint32_t s = 0; s <= smax; ++s)
+        if (rhe_clip_u8_fma(s, inv_d, c) != rhe_clip_u8((int)s - unbias, m)) return false;
+    return true;
 }
 
 // brute-force proof that the float epilogue equals the integer one for every numerator in [kmin, kmax]

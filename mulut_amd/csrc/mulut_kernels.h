@@ -40,6 +40,8 @@ struct StageArgs {
     int bias_num;           // numerator bias (127*64*M non-final, 0 final)
     float inv_d;            // fl(1/d) for the float epilogue
     int use_f32;            // float epilogue proven exact for this divisor (rhe_f32_valid)
+    float epi_c;            // fl(-unbias * fl(1/d)): addend of the fused epilogue on biased u*u-byte-row sums
+    int use_fma;            // fused form proven exact for every reachable sum (rhe_fma_valid)
     // hybrid final stage: per 64x16-tile verdict written by tile_stat_kernel (0 smooth, 1 detailed).
     // verdict_take < 0: ignore; otherwise a kernel processes only tiles whose verdict == verdict_take.
     const uint32_t *verdict;

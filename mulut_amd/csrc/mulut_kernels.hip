@@ -529,6 +529,18 @@ __device__ __forceinline__ void load_row(const void *lut, int idx, uint32_t (&ro
     }
 }
 
+// acc += x * w[WHALF] per 16-bit lane; SWAP exchanges the halves of x (reversed rotation).  One
+// v_pk_mad_u16 each, the selects are free (op_sel / op_sel_hi).
+template <int WHALF, bool SWAP>
+__device__ __forceinline__ void pk_mac(uint32_t &acc, uint32_t x, uint32_t wpk) {
+    uint32_t r;   // three-address form: the register allocator decides whether the sum stays in place
+    if constexpr (WHALF == 0 && !SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
+    if constexpr (WHALF == 1 && !SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
+    if constexpr (WHALF == 0 && SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
+    if constexpr (WHALF == 1 && SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
+    acc = r;
+}
+
 // Per-rotation SWAR accumulators with compile-time names.  u == 4 merges rotation pairs (r, r+2)
 // into one accumulator each (mulut_core.h "merged rotation pairs"): 16 VGPRs instead of 32.
 template <int U>
@@ -563,12 +575,32 @@ struct RotAcc<4> {
 #pragma unroll
         for (int k = 0; k < 4; ++k) lo02[k] = hi02[k] = lo13[k] = hi13[k] = 0;
     }
+    // one row given as ready-made 16-bit fields (rlo[k] = e(4k) | e(4k+2) << 16, rhi[k] = e(4k+1) | e(4k+3) << 16),
+    // weight = 16-bit half HALF of wpk: eight v_pk_mad_u16, the reversed rotations swap halves with op_sel
+    template <int R, int HALF>
+    __device__ __forceinline__ void mac_x(const uint32_t (&rlo)[4], const uint32_t (&rhi)[4], uint32_t wpk) {
+        static_for<0, 4>([&](auto K) {
+            constexpr int k = K;
+            if constexpr (R == 0) { pk_mac<HALF, false>(lo02[k], rlo[k], wpk); pk_mac<HALF, false>(hi02[k], rhi[k], wpk); }
+            if constexpr (R == 1) { pk_mac<HALF, false>(lo13[k], rlo[k], wpk); pk_mac<HALF, false>(hi13[k], rhi[k], wpk); }
+            if constexpr (R == 2) { pk_mac<HALF, true>(lo02[3 - k], rhi[k], wpk); pk_mac<HALF, true>(hi02[3 - k], rlo[k], wpk); }
+            if constexpr (R == 3) { pk_mac<HALF, true>(lo13[3 - k], rhi[k], wpk); pk_mac<HALF, true>(hi13[3 - k], rlo[k], wpk); }
+        });
+    }
+    // one compact (value + 128 bytes) row, weight w <= 16 in the low half: split into fields (3 full-rate ops per dword), then mac_x
     template <int R>
     __device__ __forceinline__ void fma(const uint32_t (&row)[4], uint32_t w) {
+#if MULUT_ABLATE == 4
         if constexpr (R == 0) swar_fma<4>(lo02, hi02, row, w);
         if constexpr (R == 1) swar_fma<4>(lo13, hi13, row, w);
         if constexpr (R == 2) swar_fma_rev4(lo02, hi02, row, w);
         if constexpr (R == 3) swar_fma_rev4(lo13, hi13, row, w);
+#else
+        uint32_t rlo[4], rhi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rlo[k] = row[k] & 0x00FF00FFu; rhi[k] = (row[k] >> 8) & 0x00FF00FFu; }
+        mac_x<R, 0>(rlo, rhi, w);
+#endif
     }
     // weight = 16-bit half HALF of a packed register (band kernel): one v_pk_mad_u16 per dword
     template <int R, int HALF>
@@ -1307,45 +1339,33 @@ hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mod
 // leaves room for all ten row reads of a pass in flight and for a general path that does not spill.
 // The pattern of a mode is a template parameter behind a scalar switch: every neighbour read is a
 // ds_read_u16 with an immediate offset from one per-channel window address.
-// LDS: [ band s | band d | band y : 33,312 B each ][ image tile 0 ][ image tile 1 ]  (pixel codes, 10,080 B each)
+// LDS: [ band s | band d | band y : 33,312 B each ][ image tile 0 ][ image tile 1 ]  (pixel codes, 20 x 72 x 3 x 2 B each)
 // ------------------------------------------------------------------------------------------
-constexpr int kTubeTileBytes = ((2 * 3 * (16 + 2 * kHalo) * (64 + 2 * kHalo) + 15) / 16) * 16;
+constexpr int kTubeHaloX = 4;      // the tile image starts 4 columns left of the tile: whole aligned dwords of the input row
+constexpr int kTubeTileBytes = ((2 * 3 * (16 + 2 * kHalo) * (64 + 2 * kTubeHaloX) + 15) / 16) * 16;
 constexpr int kTubeLdsBytes = 3 * kTubeBandBytes + 2 * kTubeTileBytes;
 // the packed row offsets carry this bias so that (plane address - bias) fits ds_read's 16-bit immediate
-__host__ __device__ constexpr int tube_bias(int pat) { return pat == 2 ? 32768 : 0; }
-
-// acc += x * w[WHALF] per 16-bit lane; SWAP exchanges the halves of x (reversed rotation).  One
-// v_pk_mad_u16 each, the selects are free (op_sel / op_sel_hi).
-template <int WHALF, bool SWAP>
-__device__ __forceinline__ void pk_mac(uint32_t &acc, uint32_t x, uint32_t wpk) {
-    if constexpr (WHALF == 0 && !SWAP) asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(wpk));
-    if constexpr (WHALF == 1 && !SWAP) asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(wpk));
-    if constexpr (WHALF == 0 && SWAP) asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(x), "v"(wpk));
-    if constexpr (WHALF == 1 && SWAP) asm("v_pk_mad_u16 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(x), "v"(wpk));
-}
+__host__ __device__ constexpr int tube_bias(int pat) { return pat == 2 ? 36000 : pat == 1 ? 2048 : 0; }
 
 // one row (LO + HI plane dwords) into the accumulators of rotation R, weight half HALF
 template <int R, int HALF>
 __device__ __forceinline__ void tube_mac_row(RotAcc<4> &acc, const uint4 &lo, const uint4 &hi, uint32_t wpk) {
     const uint32_t rlo[4] = {lo.x, lo.y, lo.z, lo.w}, rhi[4] = {hi.x, hi.y, hi.z, hi.w};
-    static_for<0, 4>([&](auto K) {
-        constexpr int k = K;
-        if constexpr (R == 0) { pk_mac<HALF, false>(acc.lo02[k], rlo[k], wpk); pk_mac<HALF, false>(acc.hi02[k], rhi[k], wpk); }
-        if constexpr (R == 1) { pk_mac<HALF, false>(acc.lo13[k], rlo[k], wpk); pk_mac<HALF, false>(acc.hi13[k], rhi[k], wpk); }
-        if constexpr (R == 2) { pk_mac<HALF, true>(acc.lo02[3 - k], rhi[k], wpk); pk_mac<HALF, true>(acc.hi02[3 - k], rlo[k], wpk); }
-        if constexpr (R == 3) { pk_mac<HALF, true>(acc.lo13[3 - k], rhi[k], wpk); pk_mac<HALF, true>(acc.hi13[3 - k], rlo[k], wpk); }
-    });
+    acc.template mac_x<R, HALF>(rlo, rhi, wpk);
 }
 
-// the five rows of one pass: all ten reads issued, then accumulated in order
+// the five rows of one pass: all ten reads issued, then accumulated in order.  Row 4 (vertex 1111) sits a fixed
+// 65 slots after row 0: it shares row 0's address register and differs in the immediate only.
 template <int R, int HALF, int IMM>
 __device__ __forceinline__ void tube_rows(const uint8_t *smem, const TubePair &bp, RotAcc<4> &acc) {
     uint4 lo[5], hi[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const uint32_t off = HALF ? (bp.addr[j] >> 16) : (bp.addr[j] & 0xFFFFu);
-        lo[j] = *(const uint4 *)(smem + off + IMM);
-        hi[j] = *(const uint4 *)(smem + off + (IMM + kTubePlaneBytes));
+        const uint32_t aj = bp.addr[j < 4 ? j : 0];
+        const uint32_t off = HALF ? (aj >> 16) : (aj & 0xFFFFu);
+        constexpr int kRow4 = kTubeAll * 16;
+        lo[j] = *(const uint4 *)(smem + off + (IMM + (j < 4 ? 0 : kRow4)));
+        hi[j] = *(const uint4 *)(smem + off + (IMM + kTubePlaneBytes + (j < 4 ? 0 : kRow4)));
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j) tube_mac_row<R, HALF>(acc, lo[j], hi[j], bp.w[j]);
@@ -1355,7 +1375,8 @@ __device__ __forceinline__ void tube_rows(const uint8_t *smem, const TubePair &b
 template <int PAT, int R, int PW>
 __device__ __forceinline__ void tube_pair(const StageArgs &a, const uint8_t *smem, uint32_t win, uint32_t ca, const void *lut, RotAcc<4> &acc) {
     constexpr int IMM = PAT * kTubeBandBytes - tube_bias(PAT);
-    static_assert(IMM >= 0 && IMM + kTubePlaneBytes <= 65535 && tube_bias(PAT) + kTubePlaneBytes <= 65536, "ds_read immediate / packed offset range");
+    static_assert(IMM >= 0 && IMM + kTubeAll * 16 + kTubePlaneBytes <= 65535 && tube_bias(PAT) + kTubePlaneBytes <= 65536 && tube_bias(PAT) % 16 == 0,
+                  "ds_read immediate / packed offset range");
     const uint16_t *w = (const uint16_t *)(smem + win);
     constexpr int yb = rot_dy(R, kPatDi[PAT][0], kPatDj[PAT][0]), xb = rot_dx(R, kPatDi[PAT][0], kPatDj[PAT][0]);
     constexpr int yc = rot_dy(R, kPatDi[PAT][1], kPatDj[PAT][1]), xc = rot_dx(R, kPatDi[PAT][1], kPatDj[PAT][1]);
@@ -1366,8 +1387,12 @@ __device__ __forceinline__ void tube_pair(const StageArgs &a, const uint8_t *sme
     const uint32_t pd = w[(2 + yd) * PW + 2 + xd] | ((uint32_t)w[(2 - yd) * PW + 2 - xd] << 16);
     TubePair bp;
     simplex4_tube_pair(ca, pb, pc, pd, pk_dup((uint32_t)tube_bias(PAT)), bp);
-    if (!__all(bp.t_oob == 0u)) {
-        // rare: some lane has a pass outside the tube.  Those passes take their rows from the full table in
+#if MULUT_ABLATE == 21   /* timing-only: passes outside the tube are not handled (wrong results there) */
+    if (false) {
+#else
+    if (__builtin_expect(!__all(bp.t_oob == 0u), 0)) {
+#endif
+        // rare (and marked so: register copies belong on this edge): some lane has a pass outside the tube.  Those passes take their rows from the full table in
         // global memory here, and their weights are zeroed so that the common row walk below adds nothing for
         // them (any key combination still maps to a slot inside the band, so its reads stay in range).
         const int va = pixel_value(ca);
@@ -1393,11 +1418,36 @@ __device__ __forceinline__ void tube_mode(const StageArgs &a, const uint8_t *sme
     tube_pair<PAT, 1, PW>(a, smem, win, ca, lut, acc);
 }
 
+// Epilogue of one channel straight from the pair accumulators: the block value at (sy, sx) is the field of
+// element 4 sy + sx in the (0,2) accumulators plus the field of element (3 - sx) 4 + sy in the (1,3) ones (one
+// 16-bit-select add each), then the fused cvt / fma / rndne / cvt_pk_u8.  o[sy] = the four bytes of block row sy.
+template <int E>
+__device__ __forceinline__ uint32_t tube_field(const uint32_t (&lo)[4], const uint32_t (&hi)[4]) {
+    const uint32_t word = (E & 1) ? hi[E >> 2] : lo[E >> 2];
+    return (E & 2) ? (word >> 16) : (word & 0xFFFFu);
+}
+__device__ __forceinline__ void tube_finish_rows(const StageArgs &a, RotAcc<4> &acc, uint32_t (&o)[4]) {
+    if (a.use_fma) {      // wave-uniform
+        static_for<0, 4>([&](auto SY) {
+            constexpr int sy = SY;
+            const uint32_t s0 = tube_field<4 * sy + 0>(acc.lo02, acc.hi02) + tube_field<12 + sy>(acc.lo13, acc.hi13);
+            const uint32_t s1 = tube_field<4 * sy + 1>(acc.lo02, acc.hi02) + tube_field<8 + sy>(acc.lo13, acc.hi13);
+            const uint32_t s2 = tube_field<4 * sy + 2>(acc.lo02, acc.hi02) + tube_field<4 + sy>(acc.lo13, acc.hi13);
+            const uint32_t s3 = tube_field<4 * sy + 3>(acc.lo02, acc.hi02) + tube_field<0 + sy>(acc.lo13, acc.hi13);
+            o[sy] = rhe_pack4_fma(s0, s1, s2, s3, a.inv_d, a.epi_c);
+        });
+    } else {
+        acc.finalize();
+        o[0] = finish_row4<0>(a, acc); o[1] = finish_row4<1>(a, acc);
+        o[2] = finish_row4<2>(a, acc); o[3] = finish_row4<3>(a, acc);
+    }
+}
+
 template <int OUT, int TW, int TH>
 __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArgs b) {
-    constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
+    constexpr int PW = TW + 2 * kTubeHaloX, PH = TH + 2 * kHalo;     // tile image: columns x0-4 .. x0+TW+3, rows y0-2 .. y0+TH+1
     constexpr int NT = TW * TH;
-    constexpr int PER = (3 * PH * PW + NT - 1) / NT;          // image bytes per thread and tile
+    constexpr int DW = PW / 4, PER4 = (3 * PH * DW + NT - 1) / NT;    // aligned dwords per tile row / per thread (dword path)
     static_assert(((2 * 3 * PH * PW + 15) / 16) * 16 == kTubeTileBytes, "tile buffer size");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -1417,31 +1467,61 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
     };
     const int total = a.C * PH * PW;
     const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
-    // image bytes of a tile: all loads of a thread in flight together; they are stored (as pixel codes) later
-    auto fetch = [&](int tile, uint8_t (&v)[PER]) {
+    // Planar input whose rows start on dword boundaries (the pipeline's intermediate images): a tile is fetched as
+    // aligned dwords, in flight while the previous tile is computed.  Columns left of 0 / right of W-1 replicate the
+    // edge byte of the nearest valid dword.  Any other input takes the byte path at stash time (not prefetched).
+    const bool dw_ok = a.in.sX == 1 && ((a.W | a.in.sY | a.in.sC) & 3) == 0 && (a.in.sN & 3) == 0 && (((uintptr_t)a.in.p) & 3) == 0;
+    auto fetch = [&](int tile, uint32_t (&v)[PER4]) {
+        if (!dw_ok) return;
         int n, y0, x0;
         decode_tile(a, tile, n, y0, x0, TW, TH);
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
+        for (int k = 0; k < PER4; ++k) {
             const int i = (int)threadIdx.x + k * NT;
-            const int px = i % PW, py = (i / PW) % PH, c = imin(i / (PW * PH), a.C - 1);
+            const int q = i % DW, py = (i / DW) % PH, c = imin(i / (DW * PH), a.C - 1);
             const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
-            const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
-            v[k] = *view_addr(a.in, n, c, gy, gx);
+            const int gx = imin(imax(x0 - kTubeHaloX + 4 * q, 0), a.W - 4);
+            v[k] = *(const uint32_t *)view_addr(a.in, n, c, gy, gx);
         }
     };
-    auto stash = [&](int buf, const uint8_t (&v)[PER]) {
-        uint16_t *dst = (uint16_t *)(smem + 3 * kTubeBandBytes + buf * kTubeTileBytes);
+    auto stash = [&](int tile, int buf, const uint32_t (&v)[PER4]) {
+        int n, y0, x0;
+        decode_tile(a, tile, n, y0, x0, TW, TH);
+        uint8_t *dst = smem + 3 * kTubeBandBytes + buf * kTubeTileBytes;
+        if (dw_ok) {
+            // the index math is redone from an opaque copy of the thread id: nothing but the fetched dwords themselves
+            // may stay live across the tile's computation (the compiler would otherwise park shared terms in scratch)
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = (int)threadIdx.x + k * NT;
-            if (i < total) dst[i] = (uint16_t)pixel_code(v[k]);
+            for (int k = 0; k < PER4; ++k) {
+                const int i = tid + k * NT;
+                if (i < a.C * PH * DW) {
+                    const int gx = x0 - kTubeHaloX + 4 * (i % DW);
+                    // bytes (b0,b1) / (b2,b3) into 16-bit lanes; a dword clamped at an image edge replicates the edge byte
+                    const uint32_t sel_lo = gx < 0 ? 0x0C000C00u : gx > a.W - 4 ? 0x0C030C03u : 0x0C010C00u;
+                    const uint32_t sel_hi = gx < 0 ? 0x0C000C00u : gx > a.W - 4 ? 0x0C030C03u : 0x0C030C02u;
+                    const uint32_t lo = __builtin_amdgcn_perm(0u, v[k], sel_lo), hi = __builtin_amdgcn_perm(0u, v[k], sel_hi);
+                    // (b, 0) * 0x1001 = f << 12 | b per 16-bit lane; keeping the two nibbles gives pixel_code(b)
+                    uint2 c2;
+                    c2.x = pk_mad(lo, pk_dup(0x1001u), 0u) & 0xF0F0F0F0u;
+                    c2.y = pk_mad(hi, pk_dup(0x1001u), 0u) & 0xF0F0F0F0u;
+                    *(uint2 *)(dst + 8 * i) = c2;
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < total; i += NT) {
+                const int px = i % PW, py = (i / PW) % PH, c = i / (PW * PH);
+                const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
+                const int gx = imin(imax(x0 + px - kTubeHaloX, 0), a.W - 1);
+                ((uint16_t *)dst)[i] = (uint16_t)pixel_code(*view_addr(a.in, n, c, gy, gx));
+            }
         }
     };
 
     int tile = next_tile(first);
     if (tile >= last) return;              // workgroup-uniform
-    uint8_t pix[PER];
+    uint32_t pix[PER4];
     fetch(tile, pix);
     // bands: slot = pattern id of the mode (s, d, y); absent patterns are never read
     for (int m = 0; m < a.M; ++m) {
@@ -1450,7 +1530,7 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
         uint4 *dst = (uint4 *)(smem + pat * kTubeBandBytes);
         for (int i = threadIdx.x; i < kTubeBandBytes / 16; i += NT) dst[i] = src[i];
     }
-    stash(0, pix);
+    stash(tile, 0, pix);
     __syncthreads();
 
     for (int it = 0; tile < last; ++it) {
@@ -1460,8 +1540,8 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
         decode_tile(a, tile, n, y0, x0, TW, TH);
         const int y = y0 + ty, x = x0 + tx;
         if (y < a.oy1 && x < a.W) {
-            // LDS byte address of the 5x5 window corner of this site, channel 0
-            uint32_t win = (uint32_t)(3 * kTubeBandBytes + (it & 1) * kTubeTileBytes + 2 * (ty * PW + tx));
+            // LDS byte address of the 5x5 window corner (y-2, x-2) of this site, channel 0
+            uint32_t win = (uint32_t)(3 * kTubeBandBytes + (it & 1) * kTubeTileBytes + 2 * (ty * PW + tx + kTubeHaloX - kHalo));
             uint32_t o0[4], o1[4], o2[4];     // packed output rows of the finished channels (RGB path)
 #pragma unroll
             for (int k = 0; k < 4; ++k) o0[k] = o1[k] = o2[k] = 0;
@@ -1479,11 +1559,9 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
                     else tube_mode<2, PW>(a, smem, win, ca, lut, acc);
                 }
                 if constexpr (OUT == kOutPackedRGBU4) {
-                    acc.finalize();
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { o0[k] = o1[k]; o1[k] = o2[k]; }
-                    o2[0] = finish_row4<0>(a, acc); o2[1] = finish_row4<1>(a, acc);
-                    o2[2] = finish_row4<2>(a, acc); o2[3] = finish_row4<3>(a, acc);
+                    tube_finish_rows(a, acc, o2);
                 } else {
                     uint32_t o[4];
                     finish_channel<4, OUT>(a, acc, n, c, y, x, o);
@@ -1491,7 +1569,7 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
             }
             if constexpr (OUT == kOutPackedRGBU4) store_rgb<4>(a, n, y, x, o0, o1, o2);
         }
-        if (nxt < last) stash((it + 1) & 1, pix);
+        if (nxt < last) stash(nxt, (it + 1) & 1, pix);
         __syncthreads();     // next tile published; everyone is done reading the current one
         tile = nxt;
     }

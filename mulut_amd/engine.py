@@ -3,6 +3,7 @@
 torch is used only for device memory and streams; every compute call goes to libmulut_hip.so.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -71,6 +72,10 @@ class MuLUTEngine:
     def configure(self, stages, modes, scale=4, interval=4):
         self._check(self._lib.mulut_configure(self._h, int(stages), str(modes).encode(), int(scale), int(interval)))
         self.stages, self.modes, self.scale, self.interval = int(stages), str(modes), int(scale), int(interval)
+        # MULUT_TUNING="final_stage_kernel=5,hybrid_oob_per_1024=64": A/B and profiling runs of unmodified drivers
+        for kv in filter(None, os.environ.get("MULUT_TUNING", "").split(",")):
+            k, v = kv.split("=")
+            self.set_tuning(k.strip(), int(v))
         return self
 
     def set_lut(self, stage, mode, table):

@@ -167,6 +167,81 @@ extern "C" long emul_check_band_pair(int step) {
     return bad;
 }
 
+// tube band (mulut_core.h): the slot map must be injective on the 991 tube rows and stay inside
+// [0, kTubeSlots) for EVERY key combination; the packed pair math must give, for in-tube passes, the
+// tube slots of the scalar simplex rows with the same weight per row, for every bias the kernels use.
+extern "C" long emul_check_tube_pair(int step) {
+    long bad = 0;
+    {
+        static int owner[kTubeSlots];
+        for (int i = 0; i < kTubeSlots; ++i) owner[i] = -1;
+        int rows = 0;
+        for (int A = 0; A < kL; ++A)
+            for (int B = 0; B < kL; ++B)
+                for (int C = 0; C < kL; ++C)
+                    for (int D = 0; D < kL; ++D) {
+                        const int s = tube_slot(A, B, C, D);
+                        if (s < 0 || s >= kTubeSlots) { ++bad; continue; }
+                        if (!tube_contains(A, B, C, D)) continue;
+                        ++rows;
+                        if (owner[s] != -1) ++bad;
+                        owner[s] = ((A * kL + B) * kL + C) * kL + D;
+                    }
+        if (rows != 991) ++bad;
+        // bank property: rows whose keys differ by at most one step each never share a 16-byte bank group
+        for (int a = -1; a <= 1; ++a)
+            for (int b = -1; b <= 1; ++b)
+                for (int c = -1; c <= 1; ++c)
+                    for (int d = -1; d <= 1; ++d)
+                        if ((a || b || c || d) && ((a * kTubeSA + b * kTubeSB + c * kTubeSC + d * kTubeSD) & 15) == 0) ++bad;
+    }
+    for (uint32_t bias = 0; bias <= 32768u; bias += 32768u)
+        for (int va = 0; va < 256; va += step)
+            for (int vb = 0; vb < 256; vb += step)
+                for (int vc = 0; vc < 256; vc += step)
+                    for (int vd = 0; vd < 256; vd += 1) {
+                        const int vb2 = (vb * 7 + 3) & 255, vc2 = (vc * 5 + 11) & 255, vd2 = 255 - vd;
+                        TubePair tp;
+                        simplex4_tube_pair(pixel_code(va), pixel_code(vb) | (pixel_code(vb2) << 16), pixel_code(vc) | (pixel_code(vc2) << 16),
+                                           pixel_code(vd) | (pixel_code(vd2) << 16), pk_dup(bias), tp);
+                        for (int half = 0; half < 2; ++half) {
+                            const int b = half ? vb2 : vb, c = half ? vc2 : vc, d = half ? vd2 : vd;
+                            int idx[5], w[5];
+                            simplex4(va, b, c, d, idx, w);
+                            const int ha = va >> 4, hb = b >> 4, hc = c >> 4, hd = d >> 4;
+                            const int mx = imax(imax(ha, hb), imax(hc, hd)), mn = imin(imin(ha, hb), imin(hc, hd));
+                            const bool in = mx - mn <= 1;
+                            const uint32_t t = half ? (tp.t_oob >> 16) : (tp.t_oob & 0xFFFFu);
+                            if ((t == 0u) != in) { ++bad; continue; }
+                            int wsum = 0;
+                            uint32_t rows_s[5], rows_p[5];
+                            int wt_s[5], wt_p[5];
+                            for (int j = 0; j < 5; ++j) {
+                                const int wj = (int)(half ? (tp.w[j] >> 16) : (tp.w[j] & 0xFFFFu));
+                                wsum += wj;
+                                const int A = idx[j] / kStrideA, B = (idx[j] / kStrideB) % kL, C = (idx[j] / kStrideC) % kL, D = idx[j] % kL;
+                                if (in && !tube_contains(A, B, C, D)) ++bad;
+                                rows_s[j] = (uint32_t)tube_slot(A, B, C, D) * 16u + bias;
+                                wt_s[j] = w[j];
+                                rows_p[j] = half ? (tp.addr[j] >> 16) : (tp.addr[j] & 0xFFFFu);
+                                wt_p[j] = wj;
+                                // in the tube or not, every offset the kernel would read lies inside the plane
+                                if (rows_p[j] < bias || rows_p[j] - bias > (uint32_t)(kTubePlaneBytes - 16) || (rows_p[j] & 15u)) ++bad;
+                            }
+                            for (int j = 0; j < 5; ++j) {
+                                int ws = 0, wp = 0;
+                                for (int i = 0; i < 5; ++i) {
+                                    if (rows_s[i] == rows_s[j]) ws += wt_s[i];
+                                    if (rows_p[i] == rows_s[j]) wp += wt_p[i];
+                                }
+                                if (ws != wp) ++bad;
+                            }
+                            if (wsum != kQ) ++bad;
+                        }
+                    }
+    return bad;
+}
+
 extern "C" int emul_stage(const int8_t *const *luts, const char *modes, int M, int is_last, const uint8_t *in_chw,
                           int H, int W, int C, int u, uint8_t *out_hwc) {
     if (C > 3) return -1;

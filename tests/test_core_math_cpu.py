@@ -78,6 +78,12 @@ def test_band_pair_index_math(emul):
     assert emul.emul_check_band_pair(5) == 0
 
 
+def test_tube_pair_index_math(emul):
+    """tube band of the final-stage kernel: injective slot map on its 991 rows, bank property, packed pair math"""
+    emul.emul_check_tube_pair.restype = ctypes.c_long
+    assert emul.emul_check_tube_pair(5) == 0
+
+
 def test_float_epilogue_validity_table():
     """rhe_f32_valid() outcome per mode count (documented in DESIGN.md): the GPU uses the float epilogue
     only where it is proven exact, so this is informational -- but M = 3 (sdy) must be on the fast path."""

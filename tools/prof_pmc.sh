@@ -8,6 +8,9 @@ TAG=${1:-run}; shift || true
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+# build once, outside the profiler: a profiled process has the GPU initialised and must not start hipcc
+( cd "$R" && python -c 'from mulut_amd import _native; _native.build()' ) || exit 1
+export MULUT_NO_BUILD=1
 PASSES=(
  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR"
  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"

@@ -6,6 +6,9 @@ TAG=${1:-extra}; shift || true
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+# build once, outside the profiler: a profiled process has the GPU initialised and must not start hipcc
+( cd "$R" && python -c 'from mulut_amd import _native; _native.build()' ) || exit 1
+export MULUT_NO_BUILD=1
 rocprofv3 -L > "$OUT/counters.txt" 2>&1
 PASSES=(
  "SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU"
