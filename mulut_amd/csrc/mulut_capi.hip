@@ -42,6 +42,8 @@ struct mulut_ctx {
     float epi_c = 0.0f;
     uint32_t *verdict = nullptr;   // per-tile smooth/detailed verdicts of the hybrid final stage
     size_t verdict_tiles = 0;
+    uint32_t *fix = nullptr;       // [0] = count, [16...] = pixel ids of the tube kernel's fix-up list
+    size_t fix_cap = 0;            // capacity in ids
     int first_kernel = 0;   // 1-byte-row stages: 0 window kernel, 1 the original one-site-per-read kernel
     int hybrid_oob_per_1024 = 128; // a tile is "detailed" when more than 1/8 of its (sampled) sites leave the band
     bool timing = false;
@@ -116,6 +118,7 @@ int mulut_destroy(mulut_ctx *ctx) {
     for (auto &w : ctx->ws)
         if (w) (void)hipFree(w);
     if (ctx->verdict) (void)hipFree(ctx->verdict);
+    if (ctx->fix) (void)hipFree(ctx->fix);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -292,6 +295,7 @@ static View make_view(const uint8_t *p, int layout, int rows, int W, int C, int 
 }
 
 static int ensure_verdict(mulut_ctx *ctx, size_t tiles);
+static int ensure_fix(mulut_ctx *ctx, size_t ids);
 
 // Launch one stage: input view holds LR rows [in.row0, ...), outputs for LR rows [oy0, oy1).
 static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
@@ -338,6 +342,15 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         return MULUT_OK;
     }
     const bool x = ctx->final_kernel != 2;   // compact band only on request
+    if (tube) {
+        // every pixel of the launch may end up on the fix-up list (ids are 32-bit: larger launches take the band-x kernel)
+        if ((unsigned long long)N * H * W >= (1ull << 32)) return MULUT_EUNSUPPORTED;
+        rc = ensure_fix(ctx, (size_t)N * (oy1 - oy0) * W);
+        if (rc) return rc;
+        a.fix_count = ctx->fix;
+        a.fix_list = ctx->fix + 16;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->fix, 0, sizeof(uint32_t), st));
+    }
     BandArgs b;
     for (int m = 0; m < ctx->n_modes; ++m) {
         const DevTable &t = ctx->tab[stage - 1][pattern_id(ctx->modes[m])];
@@ -361,10 +374,13 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         g.tiles_y = (oy1 - oy0 + gh - 1) / gh;
         g.verdict_take = 1;
         HIP_TRY(ctx, launch_stage_up(g, u, mode, st));
+        if (tube) HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
         return MULUT_OK;
     }
-    if (tube) HIP_TRY(ctx, launch_stage_tube(a, b, mode, ctx->num_cus, st));
-    else if (x) HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
+    if (tube) {
+        HIP_TRY(ctx, launch_stage_tube(a, b, mode, ctx->num_cus, st));
+        HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
+    } else if (x) HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
     else HIP_TRY(ctx, launch_stage_band(a, b, mode, ctx->num_cus, st));
     return MULUT_OK;
 }
@@ -380,6 +396,16 @@ static int ensure_workspace(mulut_ctx *ctx, size_t bytes) {
     ctx->ws_bytes = 0;
     for (auto &w : ctx->ws) HIP_TRY(ctx, hipMalloc((void **)&w, bytes));
     ctx->ws_bytes = bytes;
+    return MULUT_OK;
+}
+
+static int ensure_fix(mulut_ctx *ctx, size_t ids) {
+    if (ids <= ctx->fix_cap) return MULUT_OK;
+    if (ctx->fix) HIP_TRY(ctx, hipFree(ctx->fix));
+    ctx->fix = nullptr;
+    ctx->fix_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->fix, (ids + 16) * sizeof(uint32_t)));
+    ctx->fix_cap = ids;
     return MULUT_OK;
 }
 
@@ -402,6 +428,10 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
         stage_band_tile(tw, th);
         int rc = ensure_verdict(ctx, (size_t)N * ((W + tw - 1) / tw) * ((H + th - 1) / th));
         if (rc) return rc;
+        if (ctx->scale == 4 && ctx->n_modes <= 3) {
+            rc = ensure_fix(ctx, (size_t)N * H * W);
+            if (rc) return rc;
+        }
     }
     if (ctx->stages < 2) return MULUT_OK;
     return ensure_workspace(ctx, (size_t)N * H * W * C);

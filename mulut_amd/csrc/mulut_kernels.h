@@ -47,6 +47,10 @@ struct StageArgs {
     const uint32_t *verdict;
     int verdict_take;
     int vt_x, vt_y;         // verdict grid (64x16 tiles) per image
+    // tube kernel: pixels with a pass outside the tube are appended here (id = (n H + y) W + x) and recomputed by
+    // stage_up_fix_kernel; *fix_count is zeroed by the host side before the stage
+    uint32_t *fix_list;
+    uint32_t *fix_count;
 };
 
 struct PassArgs {
@@ -81,6 +85,8 @@ const char *stage_bandx_name(int out_mode);
 // mode m (LO plane then HI plane, kTubeBandBytes); no band swaps, channel-outer loops
 hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 const char *stage_tube_name(int out_mode);
+// recompute the pixels listed in a.fix_list[0 .. *a.fix_count) from the full tables (u == 4)
+hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st);
 // per-tile smooth/detailed verdict for the hybrid final stage (tiles of stage_band_tile())
 hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st);
 void stage_band_tile(int &tw, int &th);

@@ -1373,7 +1373,7 @@ __device__ __forceinline__ void tube_rows(const uint8_t *smem, const TubePair &b
 
 // rotations R and R + 2 of one site and mode.  win = LDS byte address of the site's 5x5 window corner.
 template <int PAT, int R, int PW>
-__device__ __forceinline__ void tube_pair(const StageArgs &a, const uint8_t *smem, uint32_t win, uint32_t ca, const void *lut, RotAcc<4> &acc) {
+__device__ __forceinline__ void tube_pair(const uint8_t *smem, uint32_t win, uint32_t ca, RotAcc<4> &acc, uint32_t &dirty) {
     constexpr int IMM = PAT * kTubeBandBytes - tube_bias(PAT);
     static_assert(IMM >= 0 && IMM + kTubeAll * 16 + kTubePlaneBytes <= 65535 && tube_bias(PAT) + kTubePlaneBytes <= 65536 && tube_bias(PAT) % 16 == 0,
                   "ds_read immediate / packed offset range");
@@ -1387,35 +1387,17 @@ __device__ __forceinline__ void tube_pair(const StageArgs &a, const uint8_t *sme
     const uint32_t pd = w[(2 + yd) * PW + 2 + xd] | ((uint32_t)w[(2 - yd) * PW + 2 - xd] << 16);
     TubePair bp;
     simplex4_tube_pair(ca, pb, pc, pd, pk_dup((uint32_t)tube_bias(PAT)), bp);
-#if MULUT_ABLATE == 21   /* timing-only: passes outside the tube are not handled (wrong results there) */
-    if (false) {
-#else
-    if (__builtin_expect(!__all(bp.t_oob == 0u), 0)) {
-#endif
-        // rare (and marked so: register copies belong on this edge): some lane has a pass outside the tube.  Those passes take their rows from the full table in
-        // global memory here, and their weights are zeroed so that the common row walk below adds nothing for
-        // them (any key combination still maps to a slot inside the band, so its reads stay in range).
-        const int va = pixel_value(ca);
-        uint32_t keep = 0xFFFFFFFFu;
-        if ((bp.t_oob & 0xFFFFu) != 0u) {
-            pass_global<4, R>(lut, va, pixel_value(pb & 0xFFFFu), pixel_value(pc & 0xFFFFu), pixel_value(pd & 0xFFFFu), a, acc);
-            keep &= 0xFFFF0000u;
-        }
-        if ((bp.t_oob >> 16) != 0u) {
-            pass_global<4, R + 2>(lut, va, pixel_value(pb >> 16), pixel_value(pc >> 16), pixel_value(pd >> 16), a, acc);
-            keep &= 0x0000FFFFu;
-        }
-#pragma unroll
-        for (int j = 0; j < 5; ++j) bp.w[j] &= keep;
-    }
+    // A pass outside the tube still walks the band (any key combination maps to a slot inside it, so the reads stay
+    // in range) and adds garbage; the site is marked and recomputed from the full table by stage_up_fix_kernel.
+    dirty |= bp.t_oob;
     tube_rows<R, 0, IMM>(smem, bp, acc);
     tube_rows<R + 2, 1, IMM>(smem, bp, acc);
 }
 
 template <int PAT, int PW>
-__device__ __forceinline__ void tube_mode(const StageArgs &a, const uint8_t *smem, uint32_t win, uint32_t ca, const void *lut, RotAcc<4> &acc) {
-    tube_pair<PAT, 0, PW>(a, smem, win, ca, lut, acc);
-    tube_pair<PAT, 1, PW>(a, smem, win, ca, lut, acc);
+__device__ __forceinline__ void tube_mode(const uint8_t *smem, uint32_t win, uint32_t ca, RotAcc<4> &acc, uint32_t &dirty) {
+    tube_pair<PAT, 0, PW>(smem, win, ca, acc, dirty);
+    tube_pair<PAT, 1, PW>(smem, win, ca, acc, dirty);
 }
 
 // Epilogue of one channel straight from the pair accumulators: the block value at (sy, sx) is the field of
@@ -1545,6 +1527,7 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
             uint32_t o0[4], o1[4], o2[4];     // packed output rows of the finished channels (RGB path)
 #pragma unroll
             for (int k = 0; k < 4; ++k) o0[k] = o1[k] = o2[k] = 0;
+            uint32_t dirty = 0;               // != 0: some pass of this pixel left the tube
 #pragma clang loop unroll(disable)
             for (int c = 0; c < a.C; ++c, win += 2 * PH * PW) {
                 const uint32_t ca = *(const uint16_t *)(smem + win + 2 * (2 * PW + 2));
@@ -1552,11 +1535,10 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
                 acc.clear();
                 for (int mv = 0; mv < a.M; ++mv) {
                     const int m = __builtin_amdgcn_readfirstlane(mv);
-                    const void *lut = a.lut[m];
                     const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;     // scalar
-                    if (pat == 0) tube_mode<0, PW>(a, smem, win, ca, lut, acc);
-                    else if (pat == 1) tube_mode<1, PW>(a, smem, win, ca, lut, acc);
-                    else tube_mode<2, PW>(a, smem, win, ca, lut, acc);
+                    if (pat == 0) tube_mode<0, PW>(smem, win, ca, acc, dirty);
+                    else if (pat == 1) tube_mode<1, PW>(smem, win, ca, acc, dirty);
+                    else tube_mode<2, PW>(smem, win, ca, acc, dirty);
                 }
                 if constexpr (OUT == kOutPackedRGBU4) {
 #pragma unroll
@@ -1568,11 +1550,71 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
                 }
             }
             if constexpr (OUT == kOutPackedRGBU4) store_rgb<4>(a, n, y, x, o0, o1, o2);
+            // dirty pixels go on the fix-up list: one atomic per wave (rare), compacted by lane rank
+            const unsigned long long dm = __ballot(dirty != 0u);
+            if (dm != 0ull) {
+                const int lane = (int)(threadIdx.x & 63);
+                uint32_t at = 0;
+                if (lane == __ffsll((long long)dm) - 1) at = atomicAdd(a.fix_count, (uint32_t)__popcll(dm));
+                at = (uint32_t)__shfl((int)at, __ffsll((long long)dm) - 1);
+                if (dirty != 0u) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)((n * a.H + y) * a.W + x);
+            }
         }
         if (nxt < last) stash(nxt, (it + 1) & 1, pix);
         __syncthreads();     // next tile published; everyone is done reading the current one
         tile = nxt;
     }
+}
+
+// Fix-up of the tube kernel: every listed pixel (id = (n H + y) W + x) is recomputed, all channels and passes,
+// with its rows taken from the full tables in global memory -- the arithmetic of stage_up_kernel, with the neighbours
+// read straight from the stage input.  A fixed grid walks the list; its length is read from device memory, so the
+// launch is unconditional (hipGraph-capturable) and costs a few microseconds when the list is empty.
+template <int OUT>
+__global__ void __launch_bounds__(256) stage_up_fix_kernel(StageArgs a) {
+    const uint32_t count = *a.fix_count;
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint32_t id = a.fix_list[i];
+        const int x = (int)(id % (uint32_t)a.W), y = (int)((id / (uint32_t)a.W) % (uint32_t)a.H), n = (int)(id / ((uint32_t)a.W * (uint32_t)a.H));
+        uint32_t oR[4], oG[4], oB[4];
+        for (int c = 0; c < a.C; ++c) {
+            auto px = [&](int dy, int dx) {
+                const int gy = imin(imax(y + dy, ylo), yhi), gx = imin(imax(x + dx, 0), a.W - 1);
+                return (int)*view_addr(a.in, n, c, gy, gx);
+            };
+            const int va = px(0, 0);
+            RotAcc<4> acc;
+            acc.clear();
+            for (int mv = 0; mv < a.M; ++mv) {
+                const int m = __builtin_amdgcn_readfirstlane(mv);
+                const void *lut = a.lut[m];
+                const int di0 = a.di[m][0], di1 = a.di[m][1], di2 = a.di[m][2];
+                const int dj0 = a.dj[m][0], dj1 = a.dj[m][1], dj2 = a.dj[m][2];
+                static_for<0, 4>([&](auto R) {
+                    constexpr int r = R;
+                    int dy, dx, v0, v1, v2;
+                    sample_offset(r, di0, dj0, dy, dx); v0 = px(dy, dx);
+                    sample_offset(r, di1, dj1, dy, dx); v1 = px(dy, dx);
+                    sample_offset(r, di2, dj2, dy, dx); v2 = px(dy, dx);
+                    pass_global<4, r>(lut, va, v0, v1, v2, a, acc);
+                });
+            }
+            uint32_t o[4];
+            finish_channel<4, OUT>(a, acc, n, c, y, x, o);
+            if constexpr (OUT == kOutPackedRGBU4) keep_rgb<4>(c, o, oR, oG, oB);
+        }
+        if constexpr (OUT == kOutPackedRGBU4) store_rgb<4>(a, n, y, x, oR, oG, oB);
+    }
+}
+
+hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st) {
+    if (a.C > 3 || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(4 * num_cus)), block(256);
+    if (out_mode == kOutPlanarU4) hipLaunchKernelGGL((stage_up_fix_kernel<kOutPlanarU4>), grid, block, 0, st, a);
+    else if (out_mode == kOutPackedRGBU4 && a.C == 3) hipLaunchKernelGGL((stage_up_fix_kernel<kOutPackedRGBU4>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((stage_up_fix_kernel<kOutGeneric>), grid, block, 0, st, a);
+    return hipGetLastError();
 }
 
 const char *stage_tube_name(int out_mode) {
