@@ -18,7 +18,9 @@ struct DevTable {
     void *dev = nullptr;    // full table image
     void *band = nullptr;   // diagonal band image (v_num == 16 only), kBandRows x 16 B
     void *bandx = nullptr;  // the same rows expanded to 16-bit fields, kBandRows x 32 B
-    void *tube = nullptr;   // "tube" band (keys spanning <= 2 MSB steps) expanded to 16-bit fields, two planes of kTubeSlots x 16 B
+    void *tube = nullptr;   // "tube" band (keys spanning <= 2 MSB steps): v_num 16: expanded to 16-bit fields, two planes of kTubeSlots x 16 B;
+                            // v_num 1: one dword per slot (kTube1BandBytes)
+    size_t tube_bytes = 0;
     int vnum = 0;
     size_t bytes = 0;
 };
@@ -44,7 +46,12 @@ struct mulut_ctx {
     size_t verdict_tiles = 0;
     uint32_t *fix = nullptr;       // [0] = count, [16...] = pixel ids of the tube kernel's fix-up list
     size_t fix_cap = 0;            // capacity in ids
-    int first_kernel = 0;   // 1-byte-row stages: 0 window kernel, 1 the original one-site-per-read kernel
+    int first_kernel = 0;   // 1-byte-row stages: 0 auto (tube kernel, detailed tiles to the window kernel), 1 the original
+                            // one-site-per-read kernel, 2 window kernel (full table in LDS), 3 tube kernel on every tile
+    int u1_detail_per_1024 = 256;  // a tile goes to the full-table kernel when more than this share of its 4-pixel groups spans > 1 MSB step
+    uint32_t *tlist = nullptr;     // [0] = count, [16...] = tile ids left to the full-table kernel
+    size_t tlist_cap = 0;
+    int fma1_ok = 0;               // fused float epilogue proven exact for non-final stages
     int hybrid_oob_per_1024 = 128; // a tile is "detailed" when more than 1/8 of its (sampled) sites leave the band
     bool timing = false;
     hipEvent_t ev[MULUT_MAX_STAGES + 1] = {};
@@ -119,6 +126,7 @@ int mulut_destroy(mulut_ctx *ctx) {
         if (w) (void)hipFree(w);
     if (ctx->verdict) (void)hipFree(ctx->verdict);
     if (ctx->fix) (void)hipFree(ctx->fix);
+    if (ctx->tlist) (void)hipFree(ctx->tlist);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -158,6 +166,11 @@ int mulut_configure(mulut_ctx *ctx, int stages, const char *modes, int scale, in
         ctx->epi_c = -(float)unbias * inv_d;
         ctx->fma_ok = rhe_fma_valid((uint32_t)(255 * kQ * 4 * (int)M), unbias, dm, inv_d, ctx->epi_c) ? 1 : 0;
     }
+    {   // non-final stages: clip(rhe((K + 127 d) / d)) = cvt_u8(fma(K, 1/d, 127)), K in [-128 * 16 * 4M, 127 * 16 * 4M]
+        const DivMagic dm = make_div_magic((uint32_t)stage_divisor((int)M, false));
+        const int span = 128 * kQ * 4 * (int)M;
+        ctx->fma1_ok = rhe_fma_valid_i(-span, span, stage_bias_num((int)M, false), dm, 1.0f / (float)dm.d, 127.0f) ? 1 : 0;
+    }
     ctx->configured = true;
     return MULUT_OK;
 }
@@ -192,7 +205,27 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
     HIP_TRY(ctx, hipMemcpy(t.dev, img.data(), img.size(), hipMemcpyHostToDevice));
     t.vnum = vnum;
     t.bytes = img.size();
-    if (u == 4) {
+    if (u == 1) {
+        // tube band of a 1-byte-row table: one dword per slot, the value as int16 in both halves
+        std::vector<uint32_t> tb((size_t)kTube1BandBytes / 4, 0u);
+        for (int A = 0; A < kL; ++A)
+            for (int B = imax(0, A - 2); B <= imin(kL - 1, A + 2); ++B)
+                for (int C = imax(0, A - 2); C <= imin(kL - 1, A + 2); ++C)
+                    for (int D = imax(0, A - 2); D <= imin(kL - 1, A + 2); ++D) {
+                        if (!tube_contains(A, B, C, D)) continue;
+                        const uint32_t v = (uint32_t)(uint16_t)(int16_t)host_rows[(size_t)A * kStrideA + B * kStrideB + C * kStrideC + D];
+                        tb[(size_t)tube_slot(A, B, C, D)] = v | (v << 16);
+                    }
+        if (t.tube) HIP_TRY(ctx, hipFree(t.tube));
+        t.tube = nullptr;
+        HIP_TRY(ctx, hipMalloc(&t.tube, tb.size() * 4));
+        HIP_TRY(ctx, hipMemcpy(t.tube, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
+        if (t.band) {
+            HIP_TRY(ctx, hipFree(t.band));
+            HIP_TRY(ctx, hipFree(t.bandx));
+            t.band = t.bandx = nullptr;
+        }
+    } else if (u == 4) {
         // diagonal band (mulut_core.h): rows (A,B,C,D) with B-A, C-A, D-A in [-2,2], at band_slot()
         std::vector<uint8_t> band((size_t)kBandRows * 16, 128);
         for (int A = 0; A < kL; ++A)
@@ -229,12 +262,17 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
                             tb[(size_t)kTubePlaneBytes / 4 + s4 + k] = (uint32_t)e[4 * k + 1] | ((uint32_t)e[4 * k + 3] << 16);
                         }
                     }
+        if (t.tube && t.tube_bytes != tb.size() * 4) {
+            HIP_TRY(ctx, hipFree(t.tube));
+            t.tube = nullptr;
+        }
         if (!t.tube) HIP_TRY(ctx, hipMalloc(&t.tube, tb.size() * 4));
+        t.tube_bytes = tb.size() * 4;
         HIP_TRY(ctx, hipMemcpy(t.tube, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
-    } else if (t.band) {
-        HIP_TRY(ctx, hipFree(t.band));
-        HIP_TRY(ctx, hipFree(t.bandx));
-        HIP_TRY(ctx, hipFree(t.tube));
+    } else {
+        if (t.band) HIP_TRY(ctx, hipFree(t.band));
+        if (t.bandx) HIP_TRY(ctx, hipFree(t.bandx));
+        if (t.tube) HIP_TRY(ctx, hipFree(t.tube));
         t.band = t.bandx = t.tube = nullptr;
     }
     return MULUT_OK;
@@ -296,6 +334,7 @@ static View make_view(const uint8_t *p, int layout, int rows, int W, int C, int 
 
 static int ensure_verdict(mulut_ctx *ctx, size_t tiles);
 static int ensure_fix(mulut_ctx *ctx, size_t ids);
+static int ensure_tlist(mulut_ctx *ctx, size_t tiles);
 
 // Launch one stage: input view holds LR rows [in.row0, ...), outputs for LR rows [oy0, oy1).
 static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
@@ -319,8 +358,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.bias_num = stage_bias_num(ctx->n_modes, last);
     a.inv_d = 1.0f / (float)a.div.d;
     a.use_f32 = ctx->f32_ok[last ? 1 : 0];
-    a.epi_c = ctx->epi_c;
-    a.use_fma = last ? ctx->fma_ok : 0;
+    a.epi_c = last ? ctx->epi_c : 127.0f;
+    a.use_fma = last ? ctx->fma_ok : ctx->fma1_ok;
     const bool band = u == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1;
     const bool hybrid = band && (ctx->final_kernel == 0 || ctx->final_kernel == 4 || ctx->final_kernel == 6);
     const bool tube = ctx->final_kernel == 0 || ctx->final_kernel == 5 || ctx->final_kernel == 6;
@@ -331,7 +370,31 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.tiles_x = (W + tw - 1) / tw;
     a.tiles_y = (oy1 - oy0 + th - 1) / th;
     if (u == 1) {
-        HIP_TRY(ctx, launch_stage_u1(a, st, ctx->first_kernel));
+        const bool tube1 = (ctx->first_kernel == 0 || ctx->first_kernel == 3) && ctx->n_modes <= 3 &&
+                           (unsigned long long)N * C * H * W < (1ull << 32);
+        if (!tube1) {
+            HIP_TRY(ctx, launch_stage_u1(a, st, ctx->first_kernel == 1 ? 1 : 0));
+            return MULUT_OK;
+        }
+        // tube kernel on the smooth tiles; the sites it flags are recomputed from the full tables, the tiles it leaves go
+        // to the full-table kernel -- both through device-side lists (no host synchronisation, hipGraph-capturable)
+        rc = ensure_fix(ctx, (size_t)N * C * (oy1 - oy0) * W);
+        if (rc) return rc;
+        rc = ensure_tlist(ctx, (size_t)N * a.tiles_x * a.tiles_y);
+        if (rc) return rc;
+        BandArgs b1;
+        for (int m = 0; m < ctx->n_modes; ++m) b1.band[m] = ctx->tab[stage - 1][pattern_id(ctx->modes[m])].tube;
+        a.fix_count = ctx->fix;
+        a.fix_list = ctx->fix + 16;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->fix, 0, sizeof(uint32_t), st));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->tlist, 0, sizeof(uint32_t), st));
+        const bool route = ctx->first_kernel == 0;
+        a.tile_count = ctx->tlist;
+        a.tile_list = ctx->tlist + 16;
+        a.verdict_take = route ? 0 : -1;
+        HIP_TRY(ctx, launch_stage_u1t(a, b1, (unsigned)ctx->u1_detail_per_1024, ctx->num_cus, st));
+        if (route) HIP_TRY(ctx, launch_stage_u1w_list(a, ctx->num_cus, st));
+        HIP_TRY(ctx, launch_stage_u1_fix(a, ctx->num_cus, st));
         return MULUT_OK;
     }
     int mode = kOutGeneric;
@@ -409,6 +472,16 @@ static int ensure_fix(mulut_ctx *ctx, size_t ids) {
     return MULUT_OK;
 }
 
+static int ensure_tlist(mulut_ctx *ctx, size_t tiles) {
+    if (tiles <= ctx->tlist_cap) return MULUT_OK;
+    if (ctx->tlist) HIP_TRY(ctx, hipFree(ctx->tlist));
+    ctx->tlist = nullptr;
+    ctx->tlist_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->tlist, (tiles + 16) * sizeof(uint32_t)));
+    ctx->tlist_cap = tiles;
+    return MULUT_OK;
+}
+
 static int ensure_verdict(mulut_ctx *ctx, size_t tiles) {
     if (tiles <= ctx->verdict_tiles) return MULUT_OK;
     if (ctx->verdict) HIP_TRY(ctx, hipFree(ctx->verdict));
@@ -428,9 +501,15 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
         stage_band_tile(tw, th);
         int rc = ensure_verdict(ctx, (size_t)N * ((W + tw - 1) / tw) * ((H + th - 1) / th));
         if (rc) return rc;
-        if (ctx->scale == 4 && ctx->n_modes <= 3) {
-            rc = ensure_fix(ctx, (size_t)N * H * W);
+        if (ctx->n_modes <= 3) {
+            const bool u1 = ctx->stages > 1 || ctx->scale == 1;
+            rc = ensure_fix(ctx, (size_t)N * H * W * (u1 ? (size_t)C : 1));
             if (rc) return rc;
+            if (u1) {
+                stage_u1_tile(tw, th);
+                rc = ensure_tlist(ctx, (size_t)N * ((W + tw - 1) / tw) * ((H + th - 1) / th));
+                if (rc) return rc;
+            }
         }
     }
     if (ctx->stages < 2) return MULUT_OK;
@@ -528,8 +607,18 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
         return MULUT_OK;
     }
     if (!strcmp(key, "first_stage_kernel")) {
-        if (value < 0 || value > 1) return MULUT_EINVAL;
+        if (value < 0 || value > 3) return MULUT_EINVAL;
         ctx->first_kernel = value;
+        return MULUT_OK;
+    }
+    if (!strcmp(key, "u1t_persist")) {      // experiment: persistent workgroups per CU of the 1-byte-row tube kernel (0 = one per tile)
+        if (value < 0 || value > 8) return MULUT_EINVAL;
+        g_u1t_persist = value;
+        return MULUT_OK;
+    }
+    if (!strcmp(key, "first_stage_detail_per_1024")) {
+        if (value < 0 || value > 1024) return MULUT_EINVAL;
+        ctx->u1_detail_per_1024 = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "hybrid_oob_per_1024")) {

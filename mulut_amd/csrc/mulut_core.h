@@ -422,6 +422,44 @@ MULUT_HD void simplex4_tube_pair(uint32_t ca, uint32_t pb, uint32_t pc, uint32_t
     o.t_oob = (mx - mn) & 0xFFE0FFE0u;     // differences are multiples of 16: in the tube iff 0 or 16
 }
 
+// The same pair math for tables with 1-byte rows (non-final stages): the tube band holds one dword per slot, so row
+// offsets are 4 * slot.  addr[0..3] = byte offsets of rows 0..3 (row 4 = addr[0] + 4 * 65); no bias is needed (a band is
+// 4164 bytes).  The in-tube test is left to the caller (the 1-byte-row kernel tests a whole 5x5 neighbourhood at once).
+struct TubePair1 {
+    uint32_t addr[4];
+    uint32_t w[5];
+};
+constexpr int kTube1BandBytes = ((kTubeSlots * 4 + 15) / 16) * 16;      // 4176
+MULUT_HD void simplex4_tube_pair1(uint32_t ca_pk, uint32_t pb, uint32_t pc, uint32_t pd, TubePair1 &o) {
+    constexpr uint32_t SA = kTubeSA * 4, SB = kTubeSB * 4, SC = kTubeSC * 4, SD = kTubeSD * 4;
+    const uint32_t ha16 = ca_pk & 0x00F000F0u, hb16 = pb & 0x00F000F0u, hc16 = pc & 0x00F000F0u, hd16 = pd & 0x00F000F0u;
+    uint32_t k0 = (ca_pk & 0xF000F000u) | pk_dup(SA);
+    uint32_t k1 = (pb & 0xF000F000u) | pk_dup(SB);
+    uint32_t k2 = (pc & 0xF000F000u) | pk_dup(SC);
+    uint32_t k3 = (pd & 0xF000F000u) | pk_dup(SD);
+#if !(defined(MULUT_ABLATE) && MULUT_ABLATE == 32)   /* 32 = timing-only: no sort */
+    pk_cmpx_desc(k0, k1);
+    pk_cmpx_desc(k2, k3);
+    pk_cmpx_desc(k0, k2);
+    pk_cmpx_desc(k1, k3);
+    pk_cmpx_desc(k1, k2);
+#endif
+    const uint32_t f1 = pk_shr12(k0), f2 = pk_shr12(k1), f3 = pk_shr12(k2), f4 = pk_shr12(k3);
+    // 16 * slot = (16 h) * slot stride summed over the keys (< 16 * 1041); a quarter of it is the byte offset
+    const uint32_t base16 = pk_mad(ha16, pk_dup(kTubeSA), pk_mad(hb16, pk_dup(kTubeSB), pk_mad(hc16, pk_dup(kTubeSC),
+                            pk_mad(hd16, pk_dup(kTubeSD), 0u))));
+    const uint32_t base = base16 >> 2;      // one 32-bit shift: both halves are multiples of 16, so no set bit crosses over
+    o.addr[0] = base;
+    o.addr[1] = base + (k0 & 0x0FFF0FFFu);
+    o.addr[2] = o.addr[1] + (k1 & 0x0FFF0FFFu);
+    o.addr[3] = o.addr[2] + (k2 & 0x0FFF0FFFu);
+    o.w[0] = pk_dup(kQ) - f1;
+    o.w[1] = f1 - f2;
+    o.w[2] = f2 - f3;
+    o.w[3] = f3 - f4;
+    o.w[4] = f4;
+}
+
 // ---- merged rotation pairs ----------------------------------------------------------------------------
 // Rotation r+2 maps row element e to the block position that rotation r gives element 15-e
 // (row_elem(r+2,sy,sx,4) == 15 - row_elem(r,sy,sx,4)), so the rows of rotation r+2 can be added
@@ -560,6 +598,18 @@ MULUT_HD uint32_t rhe_pack4_fma(uint32_t S0, uint32_t S1, uint32_t S2, uint32_t 
 MULUT_HD bool rhe_fma_valid(uint32_t smax, int unbias, DivMagic m, float inv_d, float c) {
     for (uint32_t s = 0; s <= smax; ++s)
         if (rhe_clip_u8_fma(s, inv_d, c) != rhe_clip_u8((int)s - unbias, m)) return false;
+    return true;
+}
+
+// the same fused form on a signed numerator K with the bias folded into the addend: clip(rhe((K + bias) / d)) as
+// cvt -> fma(K, fl(1/d), c) -> (rounding) saturating u8 convert
+MULUT_HD uint32_t rhe_clip_u8_fma_i(int K, float inv_d, float c) {
+    const float q = __builtin_rintf(__builtin_fmaf((float)K, inv_d, c));
+    return q < 0.0f ? 0u : (q > 255.0f ? 255u : (uint32_t)q);
+}
+MULUT_HD bool rhe_fma_valid_i(int kmin, int kmax, int bias, DivMagic m, float inv_d, float c) {
+    for (int k = kmin; k <= kmax; ++k)
+        if (rhe_clip_u8_fma_i(k, inv_d, c) != rhe_clip_u8(k + bias, m)) return false;
     return true;
 }
 

@@ -51,6 +51,9 @@ struct StageArgs {
     // stage_up_fix_kernel; *fix_count is zeroed by the host side before the stage
     uint32_t *fix_list;
     uint32_t *fix_count;
+    // 1-byte-row tube kernel: tiles it leaves to the full-table kernel (stage_u1w_kernel in list mode)
+    uint32_t *tile_list;
+    uint32_t *tile_count;
 };
 
 struct PassArgs {
@@ -74,6 +77,16 @@ hipError_t launch_pass(const PassArgs &a, hipStream_t st);
 // non-final (or u == 1 final) stage: tables staged in LDS, one byte out per site
 // variant 0: window kernel (four adjacent pixels per thread, neighbours from registers), 1: one site per LDS read
 hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant);
+// the same stage on the tube band (b.band[m] = dword-per-slot band of mode m, kTube1BandBytes): computes every tile
+// whose local-detail statistic is at most detail_per_1024 (all tiles when a.tile_list is null), lists the others in
+// a.tile_list and the sites that may have left the tube in a.fix_list
+hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st);
+// full-table kernel over the tiles in a.tile_list[0 .. *a.tile_count)
+hipError_t launch_stage_u1w_list(const StageArgs &a, int num_cus, hipStream_t st);
+// recompute the sites in a.fix_list[0 .. *a.fix_count) from the full tables (1-byte rows)
+hipError_t launch_stage_u1_fix(const StageArgs &a, int num_cus, hipStream_t st);
+void stage_u1t_tile(int &tw, int &th);
+extern int g_u1t_persist;
 // final stage with u in {2,3,4}: u*u bytes out per site
 hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t st);
 // final stage, u == 4, M <= 3: band tables resident in LDS, persistent workgroups

@@ -359,8 +359,17 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
     const int8_t *s_lut = (const int8_t *)smem;
     uint8_t *s_img = smem + kU1TableBytes;
 
+    // list mode (a.tile_list != null): a fixed grid walks the tiles the tube kernel left to this one
+    const bool listed = a.tile_list != nullptr;
+    const uint32_t n_listed = listed ? *a.tile_count : 0u;
+    for (uint32_t bi = blockIdx.x;; bi += gridDim.x) {
     int n, y0, x0;
-    decode_tile(a, xcd_remap(blockIdx.x, gridDim.x), n, y0, x0, TW, TH);
+    if (listed) {
+        if (bi >= n_listed) break;            // workgroup-uniform
+        decode_tile(a, (int)a.tile_list[bi], n, y0, x0, TW, TH);
+    } else {
+        decode_tile(a, xcd_remap(blockIdx.x, gridDim.x), n, y0, x0, TW, TH);
+    }
     // The table of the NEXT mode travels through registers: fetched (6 x 16 B per thread) while the current mode is
     // being computed, written to LDS between the two barriers of the swap -- the swap then costs LDS stores only.
     static_assert((kU1TableBytes / 16 + NT - 1) / NT == 6, "six 16-byte chunks of the table per thread");
@@ -409,6 +418,9 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
                 }
             }
     }
+    if (!listed) break;
+    __syncthreads();      // the next tile's image must not land while a wave still reads this one
+    }
 #undef MULUT_U1_FETCH
 }
 
@@ -416,7 +428,10 @@ constexpr int K1_TW = 64, K1_TH = 64, K1_NT = 1024, K1_SPT = 12;  // 3 ch * 64*6
 static_assert(K1_SPT * K1_NT >= 3 * K1_TW * K1_TH, "SPT too small for 3 channels");
 
 void stage_u1_tile(int &tw, int &th) { tw = K1_TW; th = K1_TH; }
-const char *stage_u1_name(int variant) { return variant == 1 ? "stage_u1_kernel" : "stage_u1w_kernel"; }
+const char *stage_u1_name(int variant) {
+    return variant == 1 ? "stage_u1_kernel" : variant == 2 ? "stage_u1w_kernel" : variant == 3 ? "stage_u1t_kernel + stage_u1_fix_kernel"
+                        : "stage_u1t_kernel (smooth tiles) + stage_u1w_kernel (detailed tiles) + stage_u1_fix_kernel";
+}
 
 hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant) {
     if (a.C > 3) return hipErrorInvalidValue;
@@ -433,6 +448,379 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant) {
     const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;
     if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(K1_NT), lds, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// K1-tube: stage with 1-byte rows on the tube band (mulut_core.h).  The band of a mode is one dword per slot
+// (the int8 value as int16 in both halves): 4,176 B, so the bands of all modes stay resident next to the image
+// tile and two 1024-thread workgroups share a CU (8 waves per SIMD, <= 64 VGPRs).  A thread owns four horizontally
+// adjacent pixels; per channel it reads its 5 x 8 window of pixel codes once (ten ds_read_b64) and every
+// neighbour pair of every mode, rotation and pixel is one v_perm_b32 of two window registers.  Rotations r and
+// r + 2 run in packed 16-bit halves (the index math of the final-stage tube kernel); the five rows of both passes
+// are dword reads, combined per row by one v_bfi and accumulated by one v_dot2_i32_i16.
+// Sites whose 5 x 5 neighbourhood spans more than one MSB step (some pass may leave the tube) are computed
+// anyway -- their reads stay inside the band -- and appended to a work list that stage_u1_fix_kernel recomputes
+// from the full tables; tiles with many such sites are not computed at all but handed to the full-table kernel
+// (stage_u1w_kernel, list mode) through a tile list.  Both lists live in device memory; nothing syncs with the host.
+// LDS: [ band s | band d | band y : 4,176 B each ][ image tile: C x 68 x 68 pixel codes ][ counters ]
+// ------------------------------------------------------------------------------------------
+constexpr int K1T_TW = 64, K1T_TH = 64, K1T_NT = 1024;
+constexpr int K1T_PW = K1T_TW + 2 * kHalo, K1T_PH = K1T_TH + 2 * kHalo;
+constexpr int kU1tTileBytes = 3 * K1T_PH * K1T_PW * 2;
+constexpr int kU1tLdsBytes = 3 * kTube1BandBytes + kU1tTileBytes + 16;
+
+// packed pair of window codes: low half = code at (R1, C1), high half = code at (R2, C2); window column c lives in
+// dword c / 2, half c % 2.  One v_perm_b32 (selector bytes 0-3 pick from the second operand, 4-7 from the first).
+template <int R1, int C1, int R2, int C2, int NW>
+__device__ __forceinline__ uint32_t win_pair(const uint32_t (&w)[5][NW]) {
+    static_assert(R1 >= 0 && R1 < 5 && R2 >= 0 && R2 < 5 && C1 >= 0 && C1 < 2 * NW && C2 >= 0 && C2 < 2 * NW, "window is 5 rows x 2 NW codes");
+    constexpr uint32_t sel = ((C1 & 1) ? 0x0302u : 0x0100u) | (((C2 & 1) ? 0x0706u : 0x0504u) << 16);
+    return __builtin_amdgcn_perm(w[R2][C2 / 2], w[R1][C1 / 2], sel);
+}
+
+// rotations R and R + 2 of pixel I (0..3) of the thread, pattern PAT
+template <int PAT, int R, int I, int NW>
+__device__ __forceinline__ void u1t_pair(const uint8_t *band, const uint32_t (&win)[5][NW], uint32_t ca_pk, int &acc) {
+    constexpr int yb = rot_dy(R, kPatDi[PAT][0], kPatDj[PAT][0]), xb = rot_dx(R, kPatDi[PAT][0], kPatDj[PAT][0]);
+    constexpr int yc = rot_dy(R, kPatDi[PAT][1], kPatDj[PAT][1]), xc = rot_dx(R, kPatDi[PAT][1], kPatDj[PAT][1]);
+    constexpr int yd = rot_dy(R, kPatDi[PAT][2], kPatDj[PAT][2]), xd = rot_dx(R, kPatDi[PAT][2], kPatDj[PAT][2]);
+#if MULUT_ABLATE == 34   /* timing-only: no neighbour perms */
+    const uint32_t pb = ca_pk + R, pc = ca_pk ^ (uint32_t)(PAT + 1), pd = ca_pk + 0x10u * I;
+#else
+    const uint32_t pb = win_pair<2 + yb, I + 2 + xb, 2 - yb, I + 2 - xb, NW>(win);
+    const uint32_t pc = win_pair<2 + yc, I + 2 + xc, 2 - yc, I + 2 - xc, NW>(win);
+    const uint32_t pd = win_pair<2 + yd, I + 2 + xd, 2 - yd, I + 2 - xd, NW>(win);
+#endif
+    TubePair1 bp;
+    simplex4_tube_pair1(ca_pk, pb, pc, pd, bp);
+    uint32_t xa[5], xb2[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint32_t aj = bp.addr[j < 4 ? j : 0];
+        constexpr int kRow4 = kTubeAll * 4;
+#if MULUT_ABLATE == 31   /* timing-only: no band reads */
+        xa[j] = aj + j; xb2[j] = aj ^ (uint32_t)j;
+#else
+        xa[j] = *(const uint32_t *)(band + (aj & 0xFFFFu) + (j < 4 ? 0 : kRow4));
+        xb2[j] = *(const uint32_t *)(band + (aj >> 16) + (j < 4 ? 0 : kRow4));
+#endif
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const uint32_t t = (xa[j] & 0x0000FFFFu) | (xb2[j] & 0xFFFF0000u);     // value of pass A | value of pass B
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, bp.w[j]), acc, false);
+    }
+}
+
+// all four passes of one mode for the pixel at window column I + 2 (I = 0, 1: the pixel loop takes two pixels per step)
+template <int PAT, int I>
+__device__ __forceinline__ void u1t_mode(const uint8_t *smem, const uint32_t (&win)[5][3], uint32_t &ca_pk, int &acc) {
+    const uint8_t *band = smem + PAT * kTube1BandBytes;
+    u1t_pair<PAT, 0, I, 3>(band, win, ca_pk, acc);
+    // one pair at a time: the second pair's index math must not be scheduled into the first (the window registers
+    // leave room for one pair's temporaries under the 64-VGPR budget of 8 waves per SIMD); the empty asm ties the
+    // second pair's anchor to the first pair's sum
+#if !defined(MULUT_VARIANT_k1ilp)
+    asm volatile("" : "+v"(acc), "+v"(ca_pk));
+#endif
+    u1t_pair<PAT, 1, I, 3>(band, win, ca_pk, acc);
+}
+
+// one pixel: all modes, then the byte
+template <int I>
+__device__ __forceinline__ uint32_t u1t_pixel(const StageArgs &a, const uint8_t *smem, const uint32_t (&win)[5][3]) {
+    int acc = 0;
+    uint32_t ca_pk = win_pair<2, I + 2, 2, I + 2, 3>(win);
+    for (int mv = 0; mv < a.M; ++mv) {
+        const int m = __builtin_amdgcn_readfirstlane(mv);
+        const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
+        if (pat == 0) u1t_mode<0, I>(smem, win, ca_pk, acc);
+        else if (pat == 1) u1t_mode<1, I>(smem, win, ca_pk, acc);
+        else u1t_mode<2, I>(smem, win, ca_pk, acc);
+    }
+    if (a.use_fma)       // wave-uniform: fused float epilogue proven exact; v_cvt_pk_u8_f32 rounds to nearest even and saturates
+        return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)acc, a.inv_d, a.epi_c), 0u, 0u);
+    return rhe_clip_u8(acc + a.bias_num, a.div);
+}
+
+// bit i set <=> the 5 x 5 neighbourhood of the thread's pixel i spans more than one MSB step (then some pass of the
+// site may leave the tube).  Column maxima / minima over the five rows first, then five adjacent columns per pixel,
+// two pixels at a time in packed halves.
+__device__ __forceinline__ uint32_t u1t_dirty(const uint32_t (&win)[5][4]) {
+    uint32_t cx[4], cn[4], mx[4], mn[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        uint32_t hi = win[0][d] & 0x00F000F0u, lo = hi;
+#pragma unroll
+        for (int q = 1; q < 5; ++q) {
+            const uint32_t h = win[q][d] & 0x00F000F0u;
+            hi = pk_max(hi, h);
+            lo = pk_min(lo, h);
+        }
+        cx[d] = hi; cn[d] = lo;
+        mx[d] = pk_max(hi, __builtin_amdgcn_alignbit(hi, hi, 16));    // both halves: max of the dword's two columns
+        mn[d] = pk_min(lo, __builtin_amdgcn_alignbit(lo, lo, 16));
+    }
+    // pixel 0: columns 0-4, pixel 1: columns 1-5 (low / high half); pixels 2, 3: columns 2-6, 3-7
+    const uint32_t x01 = pk_max(pk_max((mx[0] & 0xFFFFu) | (cx[0] & 0xFFFF0000u), mx[1]), (cx[2] & 0xFFFFu) | (mx[2] & 0xFFFF0000u));
+    const uint32_t n01 = pk_min(pk_min((mn[0] & 0xFFFFu) | (cn[0] & 0xFFFF0000u), mn[1]), (cn[2] & 0xFFFFu) | (mn[2] & 0xFFFF0000u));
+    const uint32_t x23 = pk_max(pk_max((mx[1] & 0xFFFFu) | (cx[1] & 0xFFFF0000u), mx[2]), (cx[3] & 0xFFFFu) | (mx[3] & 0xFFFF0000u));
+    const uint32_t n23 = pk_min(pk_min((mn[1] & 0xFFFFu) | (cn[1] & 0xFFFF0000u), mn[2]), (cn[3] & 0xFFFFu) | (mn[3] & 0xFFFF0000u));
+    const uint32_t d01 = (x01 - n01) & 0xFFE0FFE0u, d23 = (x23 - n23) & 0xFFE0FFE0u;     // spreads are multiples of 16
+    return ((d01 & 0xFFFFu) ? 1u : 0u) | ((d01 >> 16) ? 2u : 0u) | ((d23 & 0xFFFFu) ? 4u : 0u) | ((d23 >> 16) ? 8u : 0u);
+}
+
+// (b, 0) pairs of bytes -> pixel codes: (b, 0) * 0x1001 = f << 12 | b per 16-bit lane, then keep the two nibbles
+__device__ __forceinline__ uint32_t codes_of(uint32_t byte_pair) { return pk_mad(byte_pair, pk_dup(0x1001u), 0u) & 0xF0F0F0F0u; }
+// number of halves of a packed MSB pair... 1 if the two pixels of the pair differ by more than one MSB step
+__device__ __forceinline__ uint32_t far_apart(uint32_t a, uint32_t b) {
+    const uint32_t ha = a & 0x00F000F0u, hb = b & 0x00F000F0u;
+    uint32_t hi = pk_max(ha, hb), lo = pk_min(ha, hb);
+    hi = pk_max(hi, __builtin_amdgcn_alignbit(hi, hi, 16));
+    lo = pk_min(lo, __builtin_amdgcn_alignbit(lo, lo, 16));
+    return ((hi - lo) & 0xFFE0u) ? 1u : 0u;
+}
+
+#if defined(MULUT_VARIANT_k1ilp)
+#define K1T_WAVES 4
+#else
+#define K1T_WAVES 8
+#endif
+__global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs a, BandArgs b, uint32_t detail_per_1024) {
+    constexpr int TW = K1T_TW, TH = K1T_TH, NT = K1T_NT, PW = K1T_PW, PH = K1T_PH;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *s_tile = smem + 3 * kTube1BandBytes;
+    uint32_t *s_cnt = (uint32_t *)(smem + 3 * kTube1BandBytes + kU1tTileBytes);     // [0] detailed groups, [1] groups looked at
+
+    for (int m = 0; m < a.M; ++m) {
+        const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
+        const uint32_t *src = (const uint32_t *)b.band[m];
+        uint32_t *dst = (uint32_t *)(smem + pat * kTube1BandBytes);
+        for (int i = threadIdx.x; i < kTube1BandBytes / 4; i += NT) dst[i] = src[i];
+    }
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    const int G = gridDim.x;
+    const bool by_xcd = (G & 7) == 0;
+    const int per = (ntiles + 7) >> 3;
+    int first = by_xcd ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int last = by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, ntiles) : ntiles;
+    const int step = by_xcd ? (G >> 3) : G;
+    if (G == ntiles) { first = xcd_remap(blockIdx.x, G); last = first + 1; }     // one workgroup per tile
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    const bool al4 = ((a.W | a.in.sY) & 3) == 0 && (a.in.sN & 3) == 0 && (((uintptr_t)a.in.p) & 3) == 0;
+    const bool hwc3 = al4 && a.C == 3 && a.in.sC == 1 && a.in.sX == 3;     // packed RGB rows: 12-byte groups of four pixels
+    const bool planar = al4 && a.in.sX == 1 && (a.in.sC & 3) == 0;          // planar rows: dwords of four pixels
+    const int tx4 = (int)(threadIdx.x % (TW / 4)) * 4, ty = (int)(threadIdx.x / (TW / 4));
+
+    for (int tile = first; tile < last; tile += step) {
+        int n, y0, x0;
+        decode_tile(a, tile, n, y0, x0, TW, TH);
+        __syncthreads();      // everyone is done with the previous tile (and, first trip, the bands are staged)
+        if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+        uint32_t far = 0, seen = 0;
+        // store one group of four pixel codes (two packed pairs) of channel c: image columns gx .. gx + 3 -> tile columns gx - x0 + 2 ...
+        auto put4 = [&](int c, int row, int g, uint32_t c01, uint32_t c23) {
+            uint32_t *dst = (uint32_t *)(s_tile + 2 * ((c * PH + row) * PW + 4 * g - 2));
+            if (g > 0) dst[0] = c01;                   // tile columns 4g-2, 4g-1
+            if (4 * g + 1 < PW) dst[1] = c23;          // tile columns 4g, 4g+1
+        };
+        if (hwc3) {
+            constexpr int GR = (TW + 8) / 4;            // 18 groups cover image columns x0-4 .. x0+67
+            for (int i = threadIdx.x; i < PH * GR; i += NT) {
+                const int g = i % GR, row = i / GR;
+                const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
+                const int gx = x0 - 4 + 4 * g, cgx = imin(imax(gx, 0), a.W - 4);
+                const uint32_t *src = (const uint32_t *)view_addr(a.in, n, 0, gy, cgx);
+                const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];      // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                uint32_t r01 = __builtin_amdgcn_perm(0u, d0, 0x0C030C00u), r23 = __builtin_amdgcn_perm(d2, d1, 0x0C050C02u);
+                uint32_t g01 = __builtin_amdgcn_perm(d1, d0, 0x0C040C01u), g23 = __builtin_amdgcn_perm(d2, d1, 0x0C060C03u);
+                uint32_t b01 = __builtin_amdgcn_perm(d1, d0, 0x0C050C02u), b23 = __builtin_amdgcn_perm(0u, d2, 0x0C030C00u);
+                if (gx < 0) {                 // left of the image: every column replicates column 0
+                    r01 = r23 = pk_dup(r01 & 0xFFFFu); g01 = g23 = pk_dup(g01 & 0xFFFFu); b01 = b23 = pk_dup(b01 & 0xFFFFu);
+                } else if (gx > a.W - 4) {    // right of it: column W-1
+                    r01 = r23 = pk_dup(r23 >> 16); g01 = g23 = pk_dup(g23 >> 16); b01 = b23 = pk_dup(b23 >> 16);
+                }
+                r01 = codes_of(r01); r23 = codes_of(r23); g01 = codes_of(g01); g23 = codes_of(g23); b01 = codes_of(b01); b23 = codes_of(b23);
+                put4(0, row, g, r01, r23); put4(1, row, g, g01, g23); put4(2, row, g, b01, b23);
+                far += far_apart(r01, r23) + far_apart(g01, g23) + far_apart(b01, b23);
+                seen += 3;
+            }
+        } else if (planar) {
+            constexpr int GR = (TW + 8) / 4;
+            for (int i = threadIdx.x; i < a.C * PH * GR; i += NT) {
+                const int g = i % GR, row = (i / GR) % PH, c = i / (GR * PH);
+                const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
+                const int gx = x0 - 4 + 4 * g, cgx = imin(imax(gx, 0), a.W - 4);
+                const uint32_t d = *(const uint32_t *)view_addr(a.in, n, c, gy, cgx);
+                uint32_t p01 = __builtin_amdgcn_perm(0u, d, 0x0C010C00u), p23 = __builtin_amdgcn_perm(0u, d, 0x0C030C02u);
+                if (gx < 0) p01 = p23 = pk_dup(p01 & 0xFFFFu);
+                else if (gx > a.W - 4) p01 = p23 = pk_dup(p23 >> 16);
+                p01 = codes_of(p01); p23 = codes_of(p23);
+                put4(c, row, g, p01, p23);
+                far += far_apart(p01, p23);
+                seen += 1;
+            }
+        } else {
+            for (int i = threadIdx.x; i < a.C * PH * PW; i += NT) {
+                const int px = i % PW, row = (i / PW) % PH, c = i / (PW * PH);
+                const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
+                const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
+                ((uint16_t *)s_tile)[i] = (uint16_t)pixel_code(*view_addr(a.in, n, c, gy, gx));
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { far += __shfl_down(far, o); seen += __shfl_down(seen, o); }
+        __syncthreads();      // counters zeroed before anyone adds
+        if ((threadIdx.x & 63) == 0 && seen) { atomicAdd(&s_cnt[0], far); atomicAdd(&s_cnt[1], seen); }
+        __syncthreads();      // tile and statistic in place
+        if (a.verdict_take >= 0 && s_cnt[0] * 1024u > detail_per_1024 * s_cnt[1]) {
+            // detailed tile: the full-table kernel takes it (workgroup-uniform decision)
+            if (threadIdx.x == 0) a.tile_list[atomicAdd(a.tile_count, 1u)] = (uint32_t)tile;
+            continue;
+        }
+        const int y = y0 + ty, x = x0 + tx4;
+        if (y >= a.oy1 || x >= a.W) continue;          // (no barrier below this point inside the trip)
+#pragma clang loop unroll(disable)
+        for (int c = 0; c < a.C; ++c) {
+            uint32_t dirty;
+            {   // the 5 x 8 window of the thread's four pixels, only for the neighbourhood test
+                uint32_t win8[5][4];
+                const uint2 *row = (const uint2 *)(s_tile + 2 * ((c * PH + ty) * PW + tx4));
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const uint2 lo = row[q * (PW / 4)], hi = row[q * (PW / 4) + 1];
+                    win8[q][0] = lo.x; win8[q][1] = lo.y; win8[q][2] = hi.x; win8[q][3] = hi.y;
+                }
+#if MULUT_ABLATE == 33   /* timing-only: no neighbourhood test */
+                dirty = win8[0][0] >> 31;
+#else
+                dirty = u1t_dirty(win8);
+#endif
+            }
+            uint32_t packed = 0;
+            // two pixels per step of a real loop: their 5 x 6 window is re-read (dword-aligned), nothing of a later step
+            // can be scheduled into an earlier one
+#pragma clang loop unroll(disable)
+            for (int it = 0; it < 2; ++it) {
+                uint32_t win[5][3];
+                const uint32_t *row = (const uint32_t *)(s_tile + 2 * ((c * PH + ty) * PW + tx4 + 2 * it));
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    win[q][0] = row[q * (PW / 2)]; win[q][1] = row[q * (PW / 2) + 1]; win[q][2] = row[q * (PW / 2) + 2];
+                }
+                uint32_t b0 = u1t_pixel<0>(a, smem, win);
+#if !defined(MULUT_VARIANT_k1ilp)
+                asm volatile("" : "+v"(b0), "+v"(win[2][1]));       // the second pixel starts after the first is done
+#endif
+                const uint32_t b1 = u1t_pixel<1>(a, smem, win);
+                packed |= (b0 | (b1 << 8)) << (16 * it);
+            }
+            uint8_t *dst = const_cast<uint8_t *>(view_addr(a.out, n, c, y, x));
+            if (a.out.sX == 1 && x + 3 < a.W && (((uintptr_t)dst) & 3) == 0) {
+                *(uint32_t *)dst = packed;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (x + i < a.W) dst[i * a.out.sX] = (uint8_t)(packed >> (8 * i));
+            }
+            // sites that may have left the tube: onto the fix-up list, one atomic per wave and pixel slot (rare)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool d = ((dirty >> i) & 1u) != 0u && x + i < a.W;
+                const unsigned long long dm = __ballot(d);
+                if (dm != 0ull) {
+                    const int lane = (int)(threadIdx.x & 63), lead = __ffsll((long long)dm) - 1;
+                    uint32_t at = 0;
+                    if (lane == lead) at = atomicAdd(a.fix_count, (uint32_t)__popcll(dm));
+                    at = (uint32_t)__shfl((int)at, lead);
+                    if (d) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)(((n * a.C + c) * a.H + y) * a.W + x + i);
+                }
+            }
+        }
+    }
+}
+
+// Fix-up of the 1-byte-row tube kernel: every listed site (id = ((n C + c) H + y) W + x) is recomputed from the full
+// tables in global memory (the pass_kernel arithmetic over all modes and rotations) and its byte overwritten.
+__global__ void __launch_bounds__(256) stage_u1_fix_kernel(StageArgs a) {
+    const uint32_t count = *a.fix_count;
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        uint32_t id = a.fix_list[i];
+        const int x = (int)(id % (uint32_t)a.W); id /= (uint32_t)a.W;
+        const int y = (int)(id % (uint32_t)a.H); id /= (uint32_t)a.H;
+        const int c = (int)(id % (uint32_t)a.C), n = (int)(id / (uint32_t)a.C);
+        auto px = [&](int dy, int dx) {
+            const int gy = imin(imax(y + dy, ylo), yhi), gx = imin(imax(x + dx, 0), a.W - 1);
+            return (int)*view_addr(a.in, n, c, gy, gx);
+        };
+        const int va = px(0, 0);
+        int acc = 0;
+        for (int m = 0; m < a.M; ++m) {
+            const int8_t *lut = (const int8_t *)a.lut[m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int v[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    int dy, dx;
+                    sample_offset(r, a.di[m][k], a.dj[m][k], dy, dx);
+                    v[k] = px(dy, dx);
+                }
+                int idx[5], w[5];
+                simplex4(va, v[0], v[1], v[2], idx, w);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc += w[j] * (int)lut[idx[j]];
+            }
+        }
+        *const_cast<uint8_t *>(view_addr(a.out, n, c, y, x)) = (uint8_t)rhe_clip_u8(acc + a.bias_num, a.div);
+    }
+}
+
+void stage_u1t_tile(int &tw, int &th) { tw = K1T_TW; th = K1T_TH; }
+int g_u1t_persist = 2;      // experiment knob (mulut_set_tuning "u1t_persist")
+
+hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st) {
+    if (a.C > 3 || a.M > 3 || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)stage_u1t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
+    if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    // persist_per_cu > 0: that many persistent workgroups per CU walk XCD-contiguous tile ranges; 0: one workgroup per tile
+    const long long want = g_u1t_persist > 0 ? (long long)g_u1t_persist * num_cus : ntiles;
+    const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
+    hipLaunchKernelGGL(stage_u1t_kernel, dim3(grid), dim3(K1T_NT), (size_t)kU1tLdsBytes, st, a, b, (uint32_t)detail_per_1024);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_u1w_list(const StageArgs &a, int num_cus, hipStream_t st) {
+    if (a.C > 3 || !a.tile_list || !a.tile_count) return hipErrorInvalidValue;
+    auto kern = stage_u1w_kernel<K1_TW, K1_TH, K1_NT>;
+    const size_t lds = (size_t)kU1TableBytes + (size_t)a.C * (K1_TH + 2 * kHalo) * (K1_TW + 2 * kHalo);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
+    const unsigned grid = (unsigned)(ntiles < num_cus ? ntiles : num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(K1_NT), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_u1_fix(const StageArgs &a, int num_cus, hipStream_t st) {
+    if (!a.fix_list || !a.fix_count) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stage_u1_fix_kernel, dim3((unsigned)(4 * num_cus)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -1503,6 +1891,9 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
 
     int tile = next_tile(first);
     if (tile >= last) return;              // workgroup-uniform
+#if defined(MULUT_VARIANT_clk)
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t pix[PER4];
     fetch(tile, pix);
     // bands: slot = pattern id of the mode (s, d, y); absent patterns are never read
@@ -1564,6 +1955,9 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
         __syncthreads();     // next tile published; everyone is done reading the current one
         tile = nxt;
     }
+#if defined(MULUT_VARIANT_clk)   /* probe build: shader-clock ticks this workgroup lived, into the first bytes of the output */
+    if (blockIdx.x == 0 && threadIdx.x == 0) *(unsigned long long *)a.out.p = __builtin_amdgcn_s_memtime() - clk0;
+#endif
 }
 
 // Fix-up of the tube kernel: every listed pixel (id = (n H + y) W + x) is recomputed, all channels and passes,

@@ -129,6 +129,7 @@ int main(int argc, char **argv) {
     unsigned long long sum = 1469598103934665603ull;
     for (size_t i = 0; i < out.size(); i += 97) sum = (sum ^ out[i]) * 1099511628211ull;
     printf("checksum %016llx\n", sum);
+    if (getenv("MULUT_CLKPROBE")) printf("clock probe: %llu ticks in block 0 of the last final-stage launch\n", *(unsigned long long *)out.data());
     hipFree(din); hipFree(dout);
     mulut_destroy(ctx);
     return 0;

@@ -19,7 +19,7 @@ for (h, w) in ((150, 200), (37, 129), (270, 480)):
     want = e.pipeline(x).clone()
     e.set_tuning("first_stage_kernel", 1)
     want = e.pipeline(x).clone()
-    for first in (0, 1):
+    for first in (0, 1, 2, 3):
         for sel in (2, 3, 4, 5, 6):
             e.set_tuning("final_stage_kernel", sel).set_tuning("first_stage_kernel", first)
             got = e.pipeline(x)

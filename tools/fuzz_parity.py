@@ -65,7 +65,8 @@ def main():
         e = MuLUTEngine(0).configure(stages, modes, scale, 4).set_lut_dict(luts)
         e.set_tuning("final_stage_kernel", int(rng.integers(0, 7)))
         e.set_tuning("hybrid_oob_per_1024", int(rng.choice([0, 16, 128, 512, 1024])))
-        e.set_tuning("first_stage_kernel", int(rng.integers(0, 2)))
+        e.set_tuning("first_stage_kernel", int(rng.integers(0, 4)))
+        e.set_tuning("first_stage_detail_per_1024", int(rng.choice([0, 64, 256, 1024])))
         n = int(rng.integers(1, 4))
         imgs = np.stack([content(rng, int(rng.integers(0, 5)), h, w, C) for _ in range(n)])
         want = np.stack([c_oracle.pipeline(luts, stages, modes, scale, im) for im in imgs])
