@@ -48,8 +48,8 @@ struct mulut_ctx {
     size_t fix_cap = 0;            // capacity in ids
     int first_kernel = 0;   // 1-byte-row stages: 0 auto (tube kernel, detailed tiles to the window kernel), 1 the original
                             // one-site-per-read kernel, 2 window kernel (full table in LDS), 3 tube kernel on every tile
-    int u1_detail_per_1024 = 256;  // a tile goes to the full-table kernel when more than this share of its 4-pixel groups spans > 1 MSB step
-    uint32_t *tlist = nullptr;     // [0] = count, [16...] = tile ids left to the full-table kernel
+    int u1_detail_per_1024 = 24;   // a tile goes to the full-table kernel when more than this share of its (sampled) 4-pixel groups spans > 1 MSB step
+    uint32_t *tlist = nullptr;     // [16 + tile] = 1: the tube kernel left this tile to the full-table kernel
     size_t tlist_cap = 0;
     int fma1_ok = 0;               // fused float epilogue proven exact for non-final stages
     int hybrid_oob_per_1024 = 128; // a tile is "detailed" when more than 1/8 of its (sampled) sites leave the band
@@ -216,9 +216,12 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
                         const uint32_t v = (uint32_t)(uint16_t)(int16_t)host_rows[(size_t)A * kStrideA + B * kStrideB + C * kStrideC + D];
                         tb[(size_t)tube_slot(A, B, C, D)] = v | (v << 16);
                     }
-        if (t.tube) HIP_TRY(ctx, hipFree(t.tube));
-        t.tube = nullptr;
-        HIP_TRY(ctx, hipMalloc(&t.tube, tb.size() * 4));
+        if (t.tube && t.tube_bytes != tb.size() * 4) {
+            HIP_TRY(ctx, hipFree(t.tube));
+            t.tube = nullptr;
+        }
+        if (!t.tube) HIP_TRY(ctx, hipMalloc(&t.tube, tb.size() * 4));
+        t.tube_bytes = tb.size() * 4;
         HIP_TRY(ctx, hipMemcpy(t.tube, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
         if (t.band) {
             HIP_TRY(ctx, hipFree(t.band));
@@ -274,6 +277,7 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
         if (t.bandx) HIP_TRY(ctx, hipFree(t.bandx));
         if (t.tube) HIP_TRY(ctx, hipFree(t.tube));
         t.band = t.bandx = t.tube = nullptr;
+        t.tube_bytes = 0;
     }
     return MULUT_OK;
 }
@@ -369,6 +373,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     if (u == 1) stage_u1_tile(tw, th); else if (band) stage_band_tile(tw, th); else stage_up_tile(tw, th);
     a.tiles_x = (W + tw - 1) / tw;
     a.tiles_y = (oy1 - oy0 + th - 1) / th;
+    if (u == 1 && last) a.use_fma = 0;     // (a final stage with 1-byte rows -- scale 1 -- takes the integer epilogue)
     if (u == 1) {
         const bool tube1 = (ctx->first_kernel == 0 || ctx->first_kernel == 3) && ctx->n_modes <= 3 &&
                            (unsigned long long)N * C * H * W < (1ull << 32);
@@ -387,7 +392,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.fix_count = ctx->fix;
         a.fix_list = ctx->fix + 16;
         HIP_TRY(ctx, hipMemsetAsync(ctx->fix, 0, sizeof(uint32_t), st));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->tlist, 0, sizeof(uint32_t), st));
+        if (ctx->first_kernel == 0) HIP_TRY(ctx, hipMemsetAsync(ctx->tlist, 0, (16 + (size_t)N * a.tiles_x * a.tiles_y) * sizeof(uint32_t), st));
         const bool route = ctx->first_kernel == 0;
         a.tile_count = ctx->tlist;
         a.tile_list = ctx->tlist + 16;

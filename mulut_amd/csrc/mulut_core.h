@@ -423,20 +423,23 @@ MULUT_HD void simplex4_tube_pair(uint32_t ca, uint32_t pb, uint32_t pc, uint32_t
 }
 
 // The same pair math for tables with 1-byte rows (non-final stages): the tube band holds one dword per slot, so row
-// offsets are 4 * slot.  addr[0..3] = byte offsets of rows 0..3 (row 4 = addr[0] + 4 * 65); no bias is needed (a band is
-// 4164 bytes).  The in-tube test is left to the caller (the 1-byte-row kernel tests a whole 5x5 neighbourhood at once).
+// offsets are 4 * slot, and a stride (<= 4 * 27) fits the low byte of a sort key -- the kernel adds it to the running
+// offset with a byte-select (SDWA) add, no masking.  Pixel codes here are  code1(v) = (v & 15) << 12 | v >> 4:  with the
+// MSB in the low nibble, code1 * (16 * stride) = 16 * h * stride (mod 2^16) -- the LSB nibble multiplies out of the
+// half -- so the slot sum needs no MSB extraction either.
+//   in : k0 = anchor key pair (f << 12 | 4 * 27 per half), base_a = code1(anchor) * (16 * 27) per half, pb/pc/pd = code1 pairs
+//   out: base = byte offset of row 0 per half (row 4 = base + 4 * 65), ks[0..2] = sorted keys whose low bytes are the
+//        strides of path steps 1..3, w[5] = weights.  The in-tube test is the caller's (a 5 x 5 neighbourhood at once).
 struct TubePair1 {
-    uint32_t addr[4];
+    uint32_t base;
+    uint32_t ks[3];
     uint32_t w[5];
 };
 constexpr int kTube1BandBytes = ((kTubeSlots * 4 + 15) / 16) * 16;      // 4176
-MULUT_HD void simplex4_tube_pair1(uint32_t ca_pk, uint32_t pb, uint32_t pc, uint32_t pd, TubePair1 &o) {
-    constexpr uint32_t SA = kTubeSA * 4, SB = kTubeSB * 4, SC = kTubeSC * 4, SD = kTubeSD * 4;
-    const uint32_t ha16 = ca_pk & 0x00F000F0u, hb16 = pb & 0x00F000F0u, hc16 = pc & 0x00F000F0u, hd16 = pd & 0x00F000F0u;
-    uint32_t k0 = (ca_pk & 0xF000F000u) | pk_dup(SA);
-    uint32_t k1 = (pb & 0xF000F000u) | pk_dup(SB);
-    uint32_t k2 = (pc & 0xF000F000u) | pk_dup(SC);
-    uint32_t k3 = (pd & 0xF000F000u) | pk_dup(SD);
+MULUT_HD uint32_t pixel_code1(uint32_t v) { return ((v & 15u) << 12) | (v >> 4); }
+MULUT_HD uint32_t tube1_key(uint32_t code_pk, uint32_t stride4) { return (code_pk & 0xF000F000u) | pk_dup(stride4); }
+MULUT_HD void simplex4_tube_pair1(uint32_t k0, uint32_t base_a, uint32_t pb, uint32_t pc, uint32_t pd, TubePair1 &o) {
+    uint32_t k1 = tube1_key(pb, kTubeSB * 4), k2 = tube1_key(pc, kTubeSC * 4), k3 = tube1_key(pd, kTubeSD * 4);
 #if !(defined(MULUT_ABLATE) && MULUT_ABLATE == 32)   /* 32 = timing-only: no sort */
     pk_cmpx_desc(k0, k1);
     pk_cmpx_desc(k2, k3);
@@ -445,14 +448,11 @@ MULUT_HD void simplex4_tube_pair1(uint32_t ca_pk, uint32_t pb, uint32_t pc, uint
     pk_cmpx_desc(k1, k2);
 #endif
     const uint32_t f1 = pk_shr12(k0), f2 = pk_shr12(k1), f3 = pk_shr12(k2), f4 = pk_shr12(k3);
-    // 16 * slot = (16 h) * slot stride summed over the keys (< 16 * 1041); a quarter of it is the byte offset
-    const uint32_t base16 = pk_mad(ha16, pk_dup(kTubeSA), pk_mad(hb16, pk_dup(kTubeSB), pk_mad(hc16, pk_dup(kTubeSC),
-                            pk_mad(hd16, pk_dup(kTubeSD), 0u))));
-    const uint32_t base = base16 >> 2;      // one 32-bit shift: both halves are multiples of 16, so no set bit crosses over
-    o.addr[0] = base;
-    o.addr[1] = base + (k0 & 0x0FFF0FFFu);
-    o.addr[2] = o.addr[1] + (k1 & 0x0FFF0FFFu);
-    o.addr[3] = o.addr[2] + (k2 & 0x0FFF0FFFu);
+    // 16 * slot summed over the keys (< 16 * 1041); a quarter of it is the byte offset.  One 32-bit shift: both halves
+    // are multiples of 16, so no set bit crosses over.
+    const uint32_t base16 = pk_mad(pb, pk_dup(16 * kTubeSB), pk_mad(pc, pk_dup(16 * kTubeSC), pk_mad(pd, pk_dup(16 * kTubeSD), base_a)));
+    o.base = base16 >> 2;
+    o.ks[0] = k0; o.ks[1] = k1; o.ks[2] = k2;
     o.w[0] = pk_dup(kQ) - f1;
     o.w[1] = f1 - f2;
     o.w[2] = f2 - f3;

@@ -51,9 +51,10 @@ struct StageArgs {
     // stage_up_fix_kernel; *fix_count is zeroed by the host side before the stage
     uint32_t *fix_list;
     uint32_t *fix_count;
-    // 1-byte-row tube kernel: tiles it leaves to the full-table kernel (stage_u1w_kernel in list mode)
+    // 1-byte-row tube kernel: tile_list[tile] = 1 for the tiles it leaves to the full-table kernel (stage_u1w_kernel in
+    // list mode); zeroed by the host side before the stage
     uint32_t *tile_list;
-    uint32_t *tile_count;
+    uint32_t *tile_count;     // unused
 };
 
 struct PassArgs {
@@ -81,7 +82,7 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant);
 // whose local-detail statistic is at most detail_per_1024 (all tiles when a.tile_list is null), lists the others in
 // a.tile_list and the sites that may have left the tube in a.fix_list
 hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st);
-// full-table kernel over the tiles in a.tile_list[0 .. *a.tile_count)
+// full-table kernel over the tiles marked in a.tile_list[]
 hipError_t launch_stage_u1w_list(const StageArgs &a, int num_cus, hipStream_t st);
 // recompute the sites in a.fix_list[0 .. *a.fix_count) from the full tables (1-byte rows)
 hipError_t launch_stage_u1_fix(const StageArgs &a, int num_cus, hipStream_t st);

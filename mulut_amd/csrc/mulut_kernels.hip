@@ -351,7 +351,7 @@ __device__ __forceinline__ void u1w_mode(const int8_t *s_lut, const uint8_t *s_i
     }
 }
 
-template <int TW, int TH, int NT>
+template <int TW, int TH, int NT, bool LIST>
 __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
     constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
     static_assert(TW * TH == 4 * NT && PW % 4 == 0, "four adjacent pixels per thread, dword-aligned tile rows");
@@ -359,14 +359,22 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
     const int8_t *s_lut = (const int8_t *)smem;
     uint8_t *s_img = smem + kU1TableBytes;
 
-    // list mode (a.tile_list != null): a fixed grid walks the tiles the tube kernel left to this one
-    const bool listed = a.tile_list != nullptr;
-    const uint32_t n_listed = listed ? *a.tile_count : 0u;
-    for (uint32_t bi = blockIdx.x;; bi += gridDim.x) {
+    // list mode: a fixed grid of persistent workgroups; each walks an XCD-contiguous range of tiles (neighbouring tiles
+    // share halo lines in one L2) and takes those the tube kernel marked in a.tile_list[tile]
+    constexpr bool listed = LIST;
+    const int nt_all = a.N * a.tiles_x * a.tiles_y;
+    const int G = (int)gridDim.x;
+    const bool by_xcd = (G & 7) == 0;
+    const int per = (nt_all + 7) >> 3;
+    int t_cur = !listed ? 0 : by_xcd ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int t_last = !listed ? 1 : by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, nt_all) : nt_all;
+    const int t_step = !listed ? 1 : by_xcd ? (G >> 3) : G;
+    for (;; t_cur += t_step) {
     int n, y0, x0;
     if (listed) {
-        if (bi >= n_listed) break;            // workgroup-uniform
-        decode_tile(a, (int)a.tile_list[bi], n, y0, x0, TW, TH);
+        while (t_cur < t_last && a.tile_list[t_cur] == 0u) t_cur += t_step;       // workgroup-uniform
+        if (t_cur >= t_last) break;
+        decode_tile(a, t_cur, n, y0, x0, TW, TH);
     } else {
         decode_tile(a, xcd_remap(blockIdx.x, gridDim.x), n, y0, x0, TW, TH);
     }
@@ -435,7 +443,7 @@ const char *stage_u1_name(int variant) {
 
 hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant) {
     if (a.C > 3) return hipErrorInvalidValue;
-    auto kern = variant == 1 ? stage_u1_kernel<K1_TW, K1_TH, K1_NT, K1_SPT> : stage_u1w_kernel<K1_TW, K1_TH, K1_NT>;
+    auto kern = variant == 1 ? stage_u1_kernel<K1_TW, K1_TH, K1_NT, K1_SPT> : stage_u1w_kernel<K1_TW, K1_TH, K1_NT, false>;
     const size_t lds = (size_t)kU1TableBytes + (size_t)a.C * (K1_TH + 2 * kHalo) * (K1_TW + 2 * kHalo);
     static bool attr_set[64][2] = {};  // per device and variant: >64 KB of dynamic LDS has to be opted into
     int dev = 0;
@@ -465,7 +473,7 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant) {
 // (stage_u1w_kernel, list mode) through a tile list.  Both lists live in device memory; nothing syncs with the host.
 // LDS: [ band s | band d | band y : 4,176 B each ][ image tile: C x 68 x 68 pixel codes ][ counters ]
 // ------------------------------------------------------------------------------------------
-constexpr int K1T_TW = 64, K1T_TH = 64, K1T_NT = 1024;
+constexpr int K1T_TW = 64, K1T_TH = 64, K1T_NT = 512;      // 512 threads take the tile's 64 x 64 sites in two halves of 32 rows
 constexpr int K1T_PW = K1T_TW + 2 * kHalo, K1T_PH = K1T_TH + 2 * kHalo;
 constexpr int kU1tTileBytes = 3 * K1T_PH * K1T_PW * 2;
 constexpr int kU1tLdsBytes = 3 * kTube1BandBytes + kU1tTileBytes + 16;
@@ -479,31 +487,59 @@ __device__ __forceinline__ uint32_t win_pair(const uint32_t (&w)[5][NW]) {
     return __builtin_amdgcn_perm(w[R2][C2 / 2], w[R1][C1 / 2], sel);
 }
 
-// rotations R and R + 2 of pixel I (0..3) of the thread, pattern PAT
+// LDS read at an integer byte address (address space 3 pointers are 32-bit offsets into the workgroup's allocation)
+__device__ __forceinline__ uint32_t lds_u32(uint32_t addr) {
+    return *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)addr;
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+
+// dst = a + (byte SEL of b): one full-rate SDWA add, the stride byte of a sort key needs no masking
+template <int SEL>
+__device__ __forceinline__ uint32_t add_byte(uint32_t a, uint32_t b) {
+    uint32_t r;
+    if constexpr (SEL == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// rotations R and R + 2 of the pixel at window column I + 2, pattern PAT
 template <int PAT, int R, int I, int NW>
-__device__ __forceinline__ void u1t_pair(const uint8_t *band, const uint32_t (&win)[5][NW], uint32_t ca_pk, int &acc) {
+__device__ __forceinline__ void u1t_pair(const uint32_t (&win)[5][NW], uint32_t k0, uint32_t base_a, int &acc) {
+    constexpr int BAND = PAT * kTube1BandBytes;      // LDS byte address of this pattern's band
     constexpr int yb = rot_dy(R, kPatDi[PAT][0], kPatDj[PAT][0]), xb = rot_dx(R, kPatDi[PAT][0], kPatDj[PAT][0]);
     constexpr int yc = rot_dy(R, kPatDi[PAT][1], kPatDj[PAT][1]), xc = rot_dx(R, kPatDi[PAT][1], kPatDj[PAT][1]);
     constexpr int yd = rot_dy(R, kPatDi[PAT][2], kPatDj[PAT][2]), xd = rot_dx(R, kPatDi[PAT][2], kPatDj[PAT][2]);
 #if MULUT_ABLATE == 34   /* timing-only: no neighbour perms */
-    const uint32_t pb = ca_pk + R, pc = ca_pk ^ (uint32_t)(PAT + 1), pd = ca_pk + 0x10u * I;
+    const uint32_t pb = k0 + R, pc = k0 ^ (uint32_t)(PAT + 1), pd = k0 + 0x10u * I;
 #else
     const uint32_t pb = win_pair<2 + yb, I + 2 + xb, 2 - yb, I + 2 - xb, NW>(win);
     const uint32_t pc = win_pair<2 + yc, I + 2 + xc, 2 - yc, I + 2 - xc, NW>(win);
     const uint32_t pd = win_pair<2 + yd, I + 2 + xd, 2 - yd, I + 2 - xd, NW>(win);
 #endif
     TubePair1 bp;
-    simplex4_tube_pair1(ca_pk, pb, pc, pd, bp);
+    simplex4_tube_pair1(k0, base_a, pb, pc, pd, bp);
+    // byte offsets of rows 0..3 of both passes, unpacked: row j + 1 = row j + stride byte of sorted key j
+    uint32_t aa[4], ab[4];
+    aa[0] = bp.base & 0xFFFFu;
+    ab[0] = bp.base >> 16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        aa[j + 1] = add_byte<0>(aa[j], bp.ks[j]);
+        ab[j + 1] = add_byte<2>(ab[j], bp.ks[j]);
+    }
     uint32_t xa[5], xb2[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const uint32_t aj = bp.addr[j < 4 ? j : 0];
         constexpr int kRow4 = kTubeAll * 4;
 #if MULUT_ABLATE == 31   /* timing-only: no band reads */
-        xa[j] = aj + j; xb2[j] = aj ^ (uint32_t)j;
+        xa[j] = aa[j & 3] + j; xb2[j] = ab[j & 3] ^ (uint32_t)j;
 #else
-        xa[j] = *(const uint32_t *)(band + (aj & 0xFFFFu) + (j < 4 ? 0 : kRow4));
-        xb2[j] = *(const uint32_t *)(band + (aj >> 16) + (j < 4 ? 0 : kRow4));
+        // LDS addresses as plain integers (dynamic LDS starts at 0 -- checked at kernel entry): going through the
+        // `smem` symbol would cost one v_add of a link-time zero per read
+        xa[j] = lds_u32(aa[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
+        xb2[j] = lds_u32(ab[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
 #endif
     }
 #pragma unroll
@@ -516,29 +552,32 @@ __device__ __forceinline__ void u1t_pair(const uint8_t *band, const uint32_t (&w
 
 // all four passes of one mode for the pixel at window column I + 2 (I = 0, 1: the pixel loop takes two pixels per step)
 template <int PAT, int I>
-__device__ __forceinline__ void u1t_mode(const uint8_t *smem, const uint32_t (&win)[5][3], uint32_t &ca_pk, int &acc) {
-    const uint8_t *band = smem + PAT * kTube1BandBytes;
-    u1t_pair<PAT, 0, I, 3>(band, win, ca_pk, acc);
+__device__ __forceinline__ void u1t_mode(const uint8_t *smem, const uint32_t (&win)[5][3], uint32_t &k0, uint32_t base_a, int &acc) {
+    (void)smem;
+    u1t_pair<PAT, 0, I, 3>(win, k0, base_a, acc);
     // one pair at a time: the second pair's index math must not be scheduled into the first (the window registers
     // leave room for one pair's temporaries under the 64-VGPR budget of 8 waves per SIMD); the empty asm ties the
-    // second pair's anchor to the first pair's sum
+    // second pair's anchor key to the first pair's sum
 #if !defined(MULUT_VARIANT_k1ilp)
-    asm volatile("" : "+v"(acc), "+v"(ca_pk));
+    asm volatile("" : "+v"(acc), "+v"(k0));
 #endif
-    u1t_pair<PAT, 1, I, 3>(band, win, ca_pk, acc);
+    u1t_pair<PAT, 1, I, 3>(win, k0, base_a, acc);
 }
 
 // one pixel: all modes, then the byte
 template <int I>
 __device__ __forceinline__ uint32_t u1t_pixel(const StageArgs &a, const uint8_t *smem, const uint32_t (&win)[5][3]) {
     int acc = 0;
-    uint32_t ca_pk = win_pair<2, I + 2, 2, I + 2, 3>(win);
+    // anchor terms, the same for every mode and rotation of the pixel
+    const uint32_t ca_pk = win_pair<2, I + 2, 2, I + 2, 3>(win);
+    uint32_t k0 = tube1_key(ca_pk, kTubeSA * 4);
+    const uint32_t base_a = pk_mad(ca_pk, pk_dup(16 * kTubeSA), 0u);
     for (int mv = 0; mv < a.M; ++mv) {
         const int m = __builtin_amdgcn_readfirstlane(mv);
         const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
-        if (pat == 0) u1t_mode<0, I>(smem, win, ca_pk, acc);
-        else if (pat == 1) u1t_mode<1, I>(smem, win, ca_pk, acc);
-        else u1t_mode<2, I>(smem, win, ca_pk, acc);
+        if (pat == 0) u1t_mode<0, I>(smem, win, k0, base_a, acc);
+        else if (pat == 1) u1t_mode<1, I>(smem, win, k0, base_a, acc);
+        else u1t_mode<2, I>(smem, win, k0, base_a, acc);
     }
     if (a.use_fma)       // wave-uniform: fused float epilogue proven exact; v_cvt_pk_u8_f32 rounds to nearest even and saturates
         return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)acc, a.inv_d, a.epi_c), 0u, 0u);
@@ -552,10 +591,10 @@ __device__ __forceinline__ uint32_t u1t_dirty(const uint32_t (&win)[5][4]) {
     uint32_t cx[4], cn[4], mx[4], mn[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        uint32_t hi = win[0][d] & 0x00F000F0u, lo = hi;
+        uint32_t hi = win[0][d] & 0x000F000Fu, lo = hi;
 #pragma unroll
         for (int q = 1; q < 5; ++q) {
-            const uint32_t h = win[q][d] & 0x00F000F0u;
+            const uint32_t h = win[q][d] & 0x000F000Fu;
             hi = pk_max(hi, h);
             lo = pk_min(lo, h);
         }
@@ -568,31 +607,36 @@ __device__ __forceinline__ uint32_t u1t_dirty(const uint32_t (&win)[5][4]) {
     const uint32_t n01 = pk_min(pk_min((mn[0] & 0xFFFFu) | (cn[0] & 0xFFFF0000u), mn[1]), (cn[2] & 0xFFFFu) | (mn[2] & 0xFFFF0000u));
     const uint32_t x23 = pk_max(pk_max((mx[1] & 0xFFFFu) | (cx[1] & 0xFFFF0000u), mx[2]), (cx[3] & 0xFFFFu) | (mx[3] & 0xFFFF0000u));
     const uint32_t n23 = pk_min(pk_min((mn[1] & 0xFFFFu) | (cn[1] & 0xFFFF0000u), mn[2]), (cn[3] & 0xFFFFu) | (mn[3] & 0xFFFF0000u));
-    const uint32_t d01 = (x01 - n01) & 0xFFE0FFE0u, d23 = (x23 - n23) & 0xFFE0FFE0u;     // spreads are multiples of 16
+    const uint32_t d01 = (x01 - n01) & 0xFFFEFFFEu, d23 = (x23 - n23) & 0xFFFEFFFEu;     // spread of the MSBs > 1
     return ((d01 & 0xFFFFu) ? 1u : 0u) | ((d01 >> 16) ? 2u : 0u) | ((d23 & 0xFFFFu) ? 4u : 0u) | ((d23 >> 16) ? 8u : 0u);
 }
 
-// (b, 0) pairs of bytes -> pixel codes: (b, 0) * 0x1001 = f << 12 | b per 16-bit lane, then keep the two nibbles
-__device__ __forceinline__ uint32_t codes_of(uint32_t byte_pair) { return pk_mad(byte_pair, pk_dup(0x1001u), 0u) & 0xF0F0F0F0u; }
+// (b, 0) pairs of bytes -> code1 pairs: b * 0x1001 = f << 12 | b per 16-bit lane; >> 4 moves the MSB nibble to bits 0-3
+// and the LSB nibble to bits 8-11, where the mask drops it:  f << 12 | h
+__device__ __forceinline__ uint32_t codes_of(uint32_t byte_pair) {
+    const uint32_t x = pk_mad(byte_pair, pk_dup(0x1001u), 0u);
+    return (x & 0xF000F000u) | ((x >> 4) & 0x000F000Fu);
+}
 // number of halves of a packed MSB pair... 1 if the two pixels of the pair differ by more than one MSB step
 __device__ __forceinline__ uint32_t far_apart(uint32_t a, uint32_t b) {
-    const uint32_t ha = a & 0x00F000F0u, hb = b & 0x00F000F0u;
+    const uint32_t ha = a & 0x000F000Fu, hb = b & 0x000F000Fu;
     uint32_t hi = pk_max(ha, hb), lo = pk_min(ha, hb);
     hi = pk_max(hi, __builtin_amdgcn_alignbit(hi, hi, 16));
     lo = pk_min(lo, __builtin_amdgcn_alignbit(lo, lo, 16));
-    return ((hi - lo) & 0xFFE0u) ? 1u : 0u;
+    return ((hi - lo) & 0xFFFEu) ? 1u : 0u;
 }
 
-#if defined(MULUT_VARIANT_k1ilp)
+#if defined(MULUT_VARIANT_k1ilp) || defined(MULUT_VARIANT_k1w4)
 #define K1T_WAVES 4
 #else
-#define K1T_WAVES 8
+#define K1T_WAVES 6      // 80 VGPRs: three 512-thread workgroups per CU (8 waves per SIMD would mean 64 VGPRs and spills in the pair loop)
 #endif
 __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs a, BandArgs b, uint32_t detail_per_1024) {
     constexpr int TW = K1T_TW, TH = K1T_TH, NT = K1T_NT, PW = K1T_PW, PH = K1T_PH;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_tile = smem + 3 * kTube1BandBytes;
     uint32_t *s_cnt = (uint32_t *)(smem + 3 * kTube1BandBytes + kU1tTileBytes);     // [0] detailed groups, [1] groups looked at
+    if (lds_addr_of(smem) != 0u) return;      // the band reads assume the dynamic LDS block starts at address 0 (no static LDS here)
 
     for (int m = 0; m < a.M; ++m) {
         const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
@@ -612,14 +656,68 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
     const bool al4 = ((a.W | a.in.sY) & 3) == 0 && (a.in.sN & 3) == 0 && (((uintptr_t)a.in.p) & 3) == 0;
     const bool hwc3 = al4 && a.C == 3 && a.in.sC == 1 && a.in.sX == 3;     // packed RGB rows: 12-byte groups of four pixels
     const bool planar = al4 && a.in.sX == 1 && (a.in.sC & 3) == 0;          // planar rows: dwords of four pixels
-    const int tx4 = (int)(threadIdx.x % (TW / 4)) * 4, ty = (int)(threadIdx.x / (TW / 4));
+    const int tx4 = (int)(threadIdx.x % (TW / 4)) * 4, ty0 = (int)(threadIdx.x / (TW / 4));
 
     for (int tile = first; tile < last; tile += step) {
         int n, y0, x0;
         decode_tile(a, tile, n, y0, x0, TW, TH);
         __syncthreads();      // everyone is done with the previous tile (and, first trip, the bands are staged)
         if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
-        uint32_t far = 0, seen = 0;
+        constexpr int GR = (TW + 8) / 4;            // 18 four-pixel groups cover image columns x0-4 .. x0+67
+        // a group of four pixels of one image row, as two packed byte pairs per channel (edge columns replicated)
+        auto group_hwc = [&](int row, int g, uint32_t (&bp)[6]) {
+            const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
+            const int gx = x0 - 4 + 4 * g, cgx = imin(imax(gx, 0), a.W - 4);
+            const uint32_t *src = (const uint32_t *)view_addr(a.in, n, 0, gy, cgx);
+            const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];      // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+            bp[0] = __builtin_amdgcn_perm(0u, d0, 0x0C030C00u); bp[1] = __builtin_amdgcn_perm(d2, d1, 0x0C050C02u);
+            bp[2] = __builtin_amdgcn_perm(d1, d0, 0x0C040C01u); bp[3] = __builtin_amdgcn_perm(d2, d1, 0x0C060C03u);
+            bp[4] = __builtin_amdgcn_perm(d1, d0, 0x0C050C02u); bp[5] = __builtin_amdgcn_perm(0u, d2, 0x0C030C00u);
+            if (gx < 0) {                 // left of the image: every column replicates column 0
+                bp[0] = bp[1] = pk_dup(bp[0] & 0xFFFFu); bp[2] = bp[3] = pk_dup(bp[2] & 0xFFFFu); bp[4] = bp[5] = pk_dup(bp[4] & 0xFFFFu);
+            } else if (gx > a.W - 4) {    // right of it: column W-1
+                bp[0] = bp[1] = pk_dup(bp[1] >> 16); bp[2] = bp[3] = pk_dup(bp[3] >> 16); bp[4] = bp[5] = pk_dup(bp[5] >> 16);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bp[k] = codes_of(bp[k]);
+        };
+        auto group_planar = [&](int c, int row, int g, uint32_t &p01, uint32_t &p23) {
+            const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
+            const int gx = x0 - 4 + 4 * g, cgx = imin(imax(gx, 0), a.W - 4);
+            const uint32_t d = *(const uint32_t *)view_addr(a.in, n, c, gy, cgx);
+            p01 = __builtin_amdgcn_perm(0u, d, 0x0C010C00u); p23 = __builtin_amdgcn_perm(0u, d, 0x0C030C02u);
+            if (gx < 0) p01 = p23 = pk_dup(p01 & 0xFFFFu);
+            else if (gx > a.W - 4) p01 = p23 = pk_dup(p23 >> 16);
+            p01 = codes_of(p01); p23 = codes_of(p23);
+        };
+        if (a.verdict_take >= 0 && (hwc3 || planar)) {
+            // routing statistic on every fourth row, before the tile is loaded: the share of four-pixel groups that span
+            // more than one MSB step.  A detailed tile is handed to the full-table kernel without being staged here.
+            uint32_t far = 0, seen = 0;
+            if (hwc3) {
+                for (int i = threadIdx.x; i < (PH / 4) * GR; i += NT) {
+                    uint32_t bp[6];
+                    group_hwc(4 * (i / GR) + 1, i % GR, bp);
+                    far += far_apart(bp[0], bp[1]) + far_apart(bp[2], bp[3]) + far_apart(bp[4], bp[5]);
+                    seen += 3;
+                }
+            } else {
+                for (int i = threadIdx.x; i < a.C * (PH / 4) * GR; i += NT) {
+                    uint32_t p01, p23;
+                    group_planar(i / (GR * (PH / 4)), 4 * ((i / GR) % (PH / 4)) + 1, i % GR, p01, p23);
+                    far += far_apart(p01, p23);
+                    seen += 1;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) { far += __shfl_down(far, o); seen += __shfl_down(seen, o); }
+            __syncthreads();      // counters zeroed before anyone adds
+            if ((threadIdx.x & 63) == 0 && seen) { atomicAdd(&s_cnt[0], far); atomicAdd(&s_cnt[1], seen); }
+            __syncthreads();
+            if (s_cnt[0] * 1024u > detail_per_1024 * s_cnt[1]) {       // workgroup-uniform
+                if (threadIdx.x == 0) a.tile_list[tile] = 1u;      // verdict: left to the full-table kernel
+                continue;
+            }
+        }
         // store one group of four pixel codes (two packed pairs) of channel c: image columns gx .. gx + 3 -> tile columns gx - x0 + 2 ...
         auto put4 = [&](int c, int row, int g, uint32_t c01, uint32_t c23) {
             uint32_t *dst = (uint32_t *)(s_tile + 2 * ((c * PH + row) * PW + 4 * g - 2));
@@ -627,58 +725,31 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
             if (4 * g + 1 < PW) dst[1] = c23;          // tile columns 4g, 4g+1
         };
         if (hwc3) {
-            constexpr int GR = (TW + 8) / 4;            // 18 groups cover image columns x0-4 .. x0+67
             for (int i = threadIdx.x; i < PH * GR; i += NT) {
                 const int g = i % GR, row = i / GR;
-                const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
-                const int gx = x0 - 4 + 4 * g, cgx = imin(imax(gx, 0), a.W - 4);
-                const uint32_t *src = (const uint32_t *)view_addr(a.in, n, 0, gy, cgx);
-                const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];      // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
-                uint32_t r01 = __builtin_amdgcn_perm(0u, d0, 0x0C030C00u), r23 = __builtin_amdgcn_perm(d2, d1, 0x0C050C02u);
-                uint32_t g01 = __builtin_amdgcn_perm(d1, d0, 0x0C040C01u), g23 = __builtin_amdgcn_perm(d2, d1, 0x0C060C03u);
-                uint32_t b01 = __builtin_amdgcn_perm(d1, d0, 0x0C050C02u), b23 = __builtin_amdgcn_perm(0u, d2, 0x0C030C00u);
-                if (gx < 0) {                 // left of the image: every column replicates column 0
-                    r01 = r23 = pk_dup(r01 & 0xFFFFu); g01 = g23 = pk_dup(g01 & 0xFFFFu); b01 = b23 = pk_dup(b01 & 0xFFFFu);
-                } else if (gx > a.W - 4) {    // right of it: column W-1
-                    r01 = r23 = pk_dup(r23 >> 16); g01 = g23 = pk_dup(g23 >> 16); b01 = b23 = pk_dup(b23 >> 16);
-                }
-                r01 = codes_of(r01); r23 = codes_of(r23); g01 = codes_of(g01); g23 = codes_of(g23); b01 = codes_of(b01); b23 = codes_of(b23);
-                put4(0, row, g, r01, r23); put4(1, row, g, g01, g23); put4(2, row, g, b01, b23);
-                far += far_apart(r01, r23) + far_apart(g01, g23) + far_apart(b01, b23);
-                seen += 3;
+                uint32_t bp[6];
+                group_hwc(row, g, bp);
+                put4(0, row, g, bp[0], bp[1]); put4(1, row, g, bp[2], bp[3]); put4(2, row, g, bp[4], bp[5]);
             }
         } else if (planar) {
-            constexpr int GR = (TW + 8) / 4;
             for (int i = threadIdx.x; i < a.C * PH * GR; i += NT) {
                 const int g = i % GR, row = (i / GR) % PH, c = i / (GR * PH);
-                const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
-                const int gx = x0 - 4 + 4 * g, cgx = imin(imax(gx, 0), a.W - 4);
-                const uint32_t d = *(const uint32_t *)view_addr(a.in, n, c, gy, cgx);
-                uint32_t p01 = __builtin_amdgcn_perm(0u, d, 0x0C010C00u), p23 = __builtin_amdgcn_perm(0u, d, 0x0C030C02u);
-                if (gx < 0) p01 = p23 = pk_dup(p01 & 0xFFFFu);
-                else if (gx > a.W - 4) p01 = p23 = pk_dup(p23 >> 16);
-                p01 = codes_of(p01); p23 = codes_of(p23);
+                uint32_t p01, p23;
+                group_planar(c, row, g, p01, p23);
                 put4(c, row, g, p01, p23);
-                far += far_apart(p01, p23);
-                seen += 1;
             }
         } else {
             for (int i = threadIdx.x; i < a.C * PH * PW; i += NT) {
                 const int px = i % PW, row = (i / PW) % PH, c = i / (PW * PH);
                 const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
                 const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
-                ((uint16_t *)s_tile)[i] = (uint16_t)pixel_code(*view_addr(a.in, n, c, gy, gx));
+                ((uint16_t *)s_tile)[i] = (uint16_t)pixel_code1(*view_addr(a.in, n, c, gy, gx));
             }
         }
-        for (int o = 32; o > 0; o >>= 1) { far += __shfl_down(far, o); seen += __shfl_down(seen, o); }
-        __syncthreads();      // counters zeroed before anyone adds
-        if ((threadIdx.x & 63) == 0 && seen) { atomicAdd(&s_cnt[0], far); atomicAdd(&s_cnt[1], seen); }
-        __syncthreads();      // tile and statistic in place
-        if (a.verdict_take >= 0 && s_cnt[0] * 1024u > detail_per_1024 * s_cnt[1]) {
-            // detailed tile: the full-table kernel takes it (workgroup-uniform decision)
-            if (threadIdx.x == 0) a.tile_list[atomicAdd(a.tile_count, 1u)] = (uint32_t)tile;
-            continue;
-        }
+        __syncthreads();      // tile in place
+#pragma clang loop unroll(disable)
+        for (int half = 0; half < TH * (TW / 4) / NT; ++half) {
+        const int ty = ty0 + half * (NT / (TW / 4));
         const int y = y0 + ty, x = x0 + tx4;
         if (y >= a.oy1 || x >= a.W) continue;          // (no barrier below this point inside the trip)
 #pragma clang loop unroll(disable)
@@ -738,6 +809,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                 }
             }
         }
+        }
     }
 }
 
@@ -779,7 +851,7 @@ __global__ void __launch_bounds__(256) stage_u1_fix_kernel(StageArgs a) {
 }
 
 void stage_u1t_tile(int &tw, int &th) { tw = K1T_TW; th = K1T_TH; }
-int g_u1t_persist = 2;      // experiment knob (mulut_set_tuning "u1t_persist")
+int g_u1t_persist = 0;      // experiment knob (mulut_set_tuning "u1t_persist")
 
 hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st) {
     if (a.C > 3 || a.M > 3 || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
@@ -794,7 +866,7 @@ hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned deta
     const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
     // persist_per_cu > 0: that many persistent workgroups per CU walk XCD-contiguous tile ranges; 0: one workgroup per tile
-    const long long want = g_u1t_persist > 0 ? (long long)g_u1t_persist * num_cus : ntiles;
+    const long long want = g_u1t_persist > 0 ? (long long)g_u1t_persist * num_cus : ntiles;     // (three 512-thread workgroups fit a CU)
     const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
     hipLaunchKernelGGL(stage_u1t_kernel, dim3(grid), dim3(K1T_NT), (size_t)kU1tLdsBytes, st, a, b, (uint32_t)detail_per_1024);
     return hipGetLastError();
@@ -802,7 +874,7 @@ hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned deta
 
 hipError_t launch_stage_u1w_list(const StageArgs &a, int num_cus, hipStream_t st) {
     if (a.C > 3 || !a.tile_list || !a.tile_count) return hipErrorInvalidValue;
-    auto kern = stage_u1w_kernel<K1_TW, K1_TH, K1_NT>;
+    auto kern = stage_u1w_kernel<K1_TW, K1_TH, K1_NT, true>;
     const size_t lds = (size_t)kU1TableBytes + (size_t)a.C * (K1_TH + 2 * kHalo) * (K1_TW + 2 * kHalo);
     static bool attr_set[64] = {};
     int dev = 0;
