@@ -1,86 +1,119 @@
 #!/usr/bin/env python3
-"""bench.py -- MuLUT LUT-inference throughput on MI355X (BASELINE.json config 2).
+"""bench.py -- MuLUT LUT-inference throughput on MI355X (BASELINE.json config 2, + configs 3 and 5 on request).
 
-One "step" = one pass of the hot path (2-stage sdy x4 cascade, fused per stage) over one batch of
+One "step" = one pass of the hot path (2-stage sdy x4 cascade, one fused kernel per stage) over one batch of
 synthetic 1080p LR frames already resident in HBM: LR 1080x1920x3 -> HR 4320x7680x3 per frame.
 `value` = HR output Mpixels/s of the whole job (LR-input Mpix/s = value / 16).
 
-  python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]
 
-Multi-GPU: frames are independent units (the reference fans images out with Pool(24).map,
-sr/4_test_lut.py:257-259), so each rank processes its own batch with no data-path collective: weak
-scaling.  The oracle is imported only by the cpu_baseline leg.
+N > 1 launches N ranks itself (python -m torch.distributed.run ... bench.py, before this process touches the GPU) unless
+it already runs under torchrun (WORLD_SIZE set).  Multi-GPU: frames are independent units (the reference fans images out
+with Pool(24).map, sr/4_test_lut.py:257-259), so each rank processes its own batch with no data-path collective: weak
+scaling -- that is `value`.  The north star's other sharding -- each frame cut into one strip per GPU (+halo), the HR
+strips gathered on rank 0 over RCCL -- is timed in the same run on LR 2160x3840 batches (config 3) and reported under
+config["strips_gather"].  The oracle is imported only by the cpu_baseline leg.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mulut_amd import MuLUTEngine, load_lut_dict  # noqa: E402
-from mulut_amd.synth import natural_frames, noise_frames, real_frames  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; one VALU wave-instruction per SIMD per 4 cycles at best
+LDS_PEAK_GBS = 256 * 256 * CLOCK_GHZ   # 256 B/clk/CU for ds_read_b64/b128 (MI355X_MICROARCH.md, LDS)
 STAGES, MODES, SCALE = 2, "sdy", 4
-
-
 REAL_PNG = os.path.join(ROOT, "tests", "golden", "DIV2K_LR_X4", "0001x4.png")
+LUT_DIR = os.path.join(ROOT, "tests", "golden", "luts")
 
 
-def make_batch(dist, frames, h, w, seed):
-    if dist == "real":
-        return np.ascontiguousarray(real_frames(frames, h, w, REAL_PNG, seed))
-    gen = natural_frames if dist == "natural" else noise_frames
-    base = gen(min(frames, 2), h, w, 3, seed)
-    out = [np.roll(base[i % len(base)], (37 * (i // len(base)), 91 * (i // len(base))), axis=(0, 1))
-           for i in range(frames)]
-    return np.ascontiguousarray(np.stack(out))
+# ---------------------------------------------------------------------------------------------------------------
+# self-launch (N > 1 without torchrun): the parent never initialises the GPU
+# ---------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    from mulut_amd import _native
+    _native.build()                      # once, here: ranks must not race on the library
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MULUT_NO_BUILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stderr.write(r.stdout[-4000:])
+    sys.exit(r.returncode if r.returncode else (0 if lines else 1))
 
 
-def timed_steps(eng, x, out, steps, dist_on, step_fn=None):
-    if dist_on:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        if step_fn is None:
-            eng.pipeline(x, out=out)
-        else:
-            step_fn()
-    torch.cuda.synchronize()
-    if dist_on:
-        torch.distributed.barrier()
-    return time.perf_counter() - t0
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the oracle, timed -- never the thing measured as `value`
+# ---------------------------------------------------------------------------------------------------------------
+_POOL_LUTS = None
 
 
-def cpu_baseline(eng, luts, frame_u8, crop):
-    """The reference's CPU path, as ported in oracle/np_port.py (same operation structure: 16 corner
-    gathers + 24 masked cases in float), timed single-process on a crop x crop window of the same
-    frame; its output doubles as a parity check of the GPU result for that window."""
+def _pool_tile(job):
+    from oracle import np_port
+    img, y0, y1, x0, x1, r0, c0 = job          # img = tile + halo; [y0:y1, x0:x1] = the tile inside it
+    out = np_port.run_stages(_POOL_LUTS, STAGES, MODES, SCALE, img)
+    return r0, c0, out[y0 * SCALE:y1 * SCALE, x0 * SCALE:x1 * SCALE]
+
+
+def cpu_baseline_host(luts, frame_u8, crop):
+    """Timed before the GPU is touched (the Pool forks).  (i) oracle/np_port.py -- the reference's operation structure in
+    NumPy -- single process on a crop x crop window; (ii) the same port with a process Pool over 128x128 tiles (+4-pixel
+    halo, the reference fans out with Pool(24).map) of the whole frame on every host core; (iii) the C oracle, one core."""
+    global _POOL_LUTS
+    from multiprocessing import get_context
     from oracle import c_oracle, np_port
-    win = np.ascontiguousarray(frame_u8[:crop, :crop])
     f32 = {k: v.astype(np.float32) for k, v in luts.items()}
+    win = np.ascontiguousarray(frame_u8[:crop, :crop])
     t0 = time.perf_counter()
-    ref = np_port.run_stages(f32, STAGES, MODES, SCALE, win)
-    dt = time.perf_counter() - t0
-    gpu = eng.pipeline(torch.from_numpy(win).cuda()).cpu().numpy()
-    t1 = time.perf_counter()
+    ref_win = np_port.run_stages(f32, STAGES, MODES, SCALE, win)
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
     ref_c = c_oracle.pipeline(luts, STAGES, MODES, SCALE, win)
-    dt_c = time.perf_counter() - t1
-    return {
-        "value": round(crop * crop * SCALE * SCALE / dt / 1e6, 5), "unit": "Mpix/s", "cores": 1, "kind": "port",
-        "sample": "oracle/np_port.py (NumPy port of sr/4_test_lut.py, float, 16 gathers + 24 masked cases) on the "
-                  "top-left %dx%dx3 window of frame 0, 2-stage sdy x4, %.1f s" % (crop, crop, dt),
-        "matches_gpu": bool(np.array_equal(ref, gpu) and np.array_equal(ref_c, gpu)),
-        "c_oracle_value": round(crop * crop * SCALE * SCALE / dt_c / 1e6, 4),
+    dtc = time.perf_counter() - t0
+    H, W = frame_u8.shape[:2]
+    T, halo = 128, 2 * STAGES
+    jobs = []
+    for r0 in range(0, H, T):
+        for c0 in range(0, W, T):
+            ya, yb = max(0, r0 - halo), min(H, r0 + T + halo)
+            xa, xb = max(0, c0 - halo), min(W, c0 + T + halo)
+            jobs.append((np.ascontiguousarray(frame_u8[ya:yb, xa:xb]), r0 - ya, min(H, r0 + T) - ya, c0 - xa, min(W, c0 + T) - xa, r0, c0))
+    cores = max(1, min(os.cpu_count() or 1, len(jobs)))
+    _POOL_LUTS = f32
+    full = np.empty((H * SCALE, W * SCALE, frame_u8.shape[2]), np.uint8)
+    t0 = time.perf_counter()
+    with get_context("fork").Pool(cores) as pool:
+        for r0, c0, tile in pool.imap_unordered(_pool_tile, jobs, chunksize=1):
+            full[r0 * SCALE:r0 * SCALE + tile.shape[0], c0 * SCALE:c0 * SCALE + tile.shape[1]] = tile
+    dtp = time.perf_counter() - t0
+    rec = {
+        "value": round(H * W * SCALE * SCALE / dtp / 1e6, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
+        "sample": "oracle/np_port.py (NumPy port of sr/4_test_lut.py: float, 16 corner gathers + 24 masked cases per pass) on "
+                  "frame 0 (LR %dx%dx3), multiprocessing Pool over %d tiles of 128x128 (+%d-pixel halo) on %d processes, %.1f s"
+                  % (H, W, len(jobs), halo, cores, dtp),
+        "single_core_value": round(crop * crop * SCALE * SCALE / dt1 / 1e6, 5),
+        "single_core_sample": "the same port, one process, top-left %dx%dx3 window of frame 0, %.1f s" % (crop, crop, dt1),
+        "c_oracle_single_core_value": round(crop * crop * SCALE * SCALE / dtc / 1e6, 4),
         "cpu_model": _cpu_model(), "host_cores": os.cpu_count(),
+        # (the window is a stand-alone image: its last 2 x stages columns / rows see its own edge replication, the frame's do not)
+        "tiles_match_window": bool(np.array_equal(full[:(crop - halo) * SCALE, :(crop - halo) * SCALE], ref_win[:(crop - halo) * SCALE, :(crop - halo) * SCALE])
+                                   and np.array_equal(ref_c, ref_win)),
     }
+    return rec, full
 
 
 def _cpu_model():
@@ -93,16 +126,29 @@ def _cpu_model():
     return "unknown"
 
 
-def load_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def load_profile_json(name, workload=None):
+    """Profiler-derived per-launch figures (profiles/<name>): valid only for the build they were measured on."""
+    from mulut_amd import _native
     try:
-        rec = json.load(open(path))
-        if rec.get("workload") == workload:
-            return rec.get("final_stage_bytes_per_launch")
+        rec = json.load(open(os.path.join(ROOT, "profiles", name)))
     except (OSError, ValueError):
-        pass
-    return None
+        return None
+    if rec.get("source_hash") != _native.source_hash():
+        return None
+    if workload is not None and rec.get("workload") != workload:
+        return None
+    return rec
+
+
+def make_batch(dist, frames, h, w, seed):
+    from mulut_amd.synth import natural_frames, noise_frames, real_frames
+    if dist == "real":
+        return np.ascontiguousarray(real_frames(frames, h, w, REAL_PNG, seed))
+    gen = natural_frames if dist == "natural" else noise_frames
+    base = gen(min(frames, 2), h, w, 3, seed)
+    out = [np.roll(base[i % len(base)], (37 * (i // len(base)), 91 * (i // len(base))), axis=(0, 1))
+           for i in range(frames)]
+    return np.ascontiguousarray(np.stack(out))
 
 
 def main():
@@ -116,71 +162,93 @@ def main():
     ap.add_argument("--dist", choices=["natural", "noise", "real"], default="natural",
                     help="natural: smooth synthetic field (headline); noise: uniform random bytes (worst case); "
                          "real: the DIV2K LR photo the reference ships, mirror-tiled")
-    ap.add_argument("--cpu-crop", type=int, default=512, help="window edge for the CPU baseline (0 = skip)")
-    ap.add_argument("--skip-other", action="store_true", help="do not also time the other input distribution")
-    ap.add_argument("--shard", choices=["frames", "strips"], default="frames",
-                    help="frames: each GPU owns whole frames, no collective (default); strips: every frame is cut "
-                         "into one strip per GPU (+4-row halo) and the HR strips are gathered on rank 0 over RCCL")
+    ap.add_argument("--cpu-crop", type=int, default=512, help="window edge for the single-core CPU baseline (0 = skip the CPU legs)")
+    ap.add_argument("--skip-other", action="store_true", help="do not also time the other input distributions")
+    ap.add_argument("--skip-strips", action="store_true", help="N > 1: do not also time the strips + gather sharding (config 3)")
+    ap.add_argument("--strip-frames", type=int, default=4, help="LR 2160x3840 frames per step of the strips + gather leg")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5],
+                    help="2: headline (2-stage sdy x4); 5: deep cascade (4-stage sdy x2, seeded synthetic tables), eager vs hipGraph")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    # one rank per GPU; on a box with fewer GPUs than ranks (1-GPU rehearsal of the N > 1 path with
-    # MULUT_BENCH_BACKEND=gloo) ranks share devices
-    local = local % max(1, torch.cuda.device_count())
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d: reporting n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
+
+    from mulut_amd import load_lut_dict
+    luts = load_lut_dict(LUT_DIR, STAGES, MODES, SCALE, 4, "LUT_ft")
+    F, H, W = args.frames, args.lr_h, args.lr_w
+    host = make_batch(args.dist, F, H, W, seed=rank)
+
+    # CPU legs first: the Pool forks, which must happen before this process initialises the GPU
+    cpu_rec = cpu_full = None
+    if world == 1 and args.cpu_crop > 0 and args.config == 2:
+        cpu_rec, cpu_full = cpu_baseline_host(luts, host[0], min(args.cpu_crop, H, W))
+
+    import torch
+    from mulut_amd import MuLUTEngine
+    local = local % max(1, torch.cuda.device_count())     # 1-GPU rehearsals of the N > 1 path (MULUT_BENCH_BACKEND=gloo) share the device
     torch.cuda.set_device(local)
+    backend = os.environ.get("MULUT_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MULUT_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             torch.distributed.init_process_group(backend)
 
-    luts = load_lut_dict(os.path.join(ROOT, "tests", "golden", "luts"), STAGES, MODES, SCALE, 4, "LUT_ft")
+    def barrier_sync():
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps):
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if dist_on:
+            torch.distributed.barrier()
+        el = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    if args.config == 5:
+        return config5(args, world, rank, local, timed)
+
     eng = MuLUTEngine(local).configure(STAGES, MODES, SCALE, 4).set_lut_dict(luts)
-    F, H, W = args.frames, args.lr_h, args.lr_w
     eng.reserve(F, H, W, 3)
-    host = make_batch(args.dist, F, H, W, seed=rank)
     x = torch.from_numpy(host).cuda()
     out = torch.empty((F, H * SCALE, W * SCALE, 3), dtype=torch.uint8, device=x.device)
-
-    step_fn = None
-    if args.shard == "strips" and dist_on:
-        from mulut_amd.dist import sr_strips
-        # strong scaling over one batch: every rank holds the same F frames and produces 1/world of the rows
-        torch.manual_seed(0)
-        x = torch.from_numpy(make_batch(args.dist, F, H, W, seed=0)).cuda()
-
-        def step_fn():
-            return sr_strips(x, lambda band, r0, y0, y1, hh: eng.pipeline_rows(band, r0, y0, y1, hh), SCALE, eng.halo,
-                             dst=0)
     for _ in range(args.warmup):
-        step_fn() if step_fn else eng.pipeline(x, out=out)
-    elapsed = timed_steps(eng, x, out, args.steps, dist_on, step_fn)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=x.device)
-    if dist_on:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t.item())
+        eng.pipeline(x, out=out)
+    elapsed = timed(lambda: eng.pipeline(x, out=out), args.steps)
+    value = world * F * H * SCALE * W * SCALE * args.steps / elapsed / 1e6
+    ms_step = elapsed / args.steps * 1e3
 
-    strips = step_fn is not None
-    hr_pix = (1 if strips else world) * F * H * SCALE * W * SCALE * args.steps
-    value = hr_pix / elapsed / 1e6
+    if cpu_rec is not None:
+        cpu_rec["matches_gpu"] = bool(np.array_equal(out[0].cpu().numpy(), cpu_full))
+        del cpu_full
 
-    # per-kernel device time: HIP events recorded around each stage launch on the launch stream
+    # per-stage and per-dominant-kernel device time: HIP events the library records on the launch stream
     eng.set_stage_timing(True)
-    per_stage = []
+    per_stage, per_kernel = [], []
     for _ in range(args.steps):
         eng.pipeline(x, out=out)
         per_stage.append(eng.last_stage_ms())
+        per_kernel.append(eng.last_kernel_ms())
     eng.set_stage_timing(False)
     ms_stage = np.mean(np.asarray(per_stage), axis=0)
+    ms_kernel = np.mean(np.asarray(per_kernel), axis=0)
 
-    # the other input distribution, same number of steps (reported beside the headline)
     others = {}
     if not args.skip_other:
         for other in ("natural", "noise", "real"):
@@ -189,43 +257,185 @@ def main():
             x2 = torch.from_numpy(make_batch(other, F, H, W, seed=rank)).cuda()
             for _ in range(2):
                 eng.pipeline(x2, out=out)
-            el2 = timed_steps(eng, x2, out, args.steps, dist_on)
-            t2 = torch.tensor([el2], dtype=torch.float64, device=x.device)
-            if dist_on:
-                torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MAX)
-            others[other] = world * F * H * SCALE * W * SCALE * args.steps / float(t2.item()) / 1e6
+            el2 = timed(lambda: eng.pipeline(x2, out=out), max(2, args.steps // 2))
+            others[other] = world * F * H * SCALE * W * SCALE * max(2, args.steps // 2) / el2 / 1e6
             del x2
+
+    # config 3: LR 2160x3840 frames.  N = 1: whole frames on the one GPU.  N > 1: every frame cut into one strip per rank
+    # (+halo), cascade per strip, HR strips sent point to point (RCCL) into the frame on rank 0; the gather of batch k
+    # overlaps the compute of batch k + 1.
+    strips = None
+    if not args.skip_strips:
+        strips = config3(args, eng, world, rank, dist_on, backend, timed)
 
     if rank == 0:
         sites = F * H * W * 3                                   # LR samples per launch
-        lut_final = 3 * 83521 * 16
-        alg_k2 = sites * (1 + SCALE * SCALE) + lut_final        # 17 B per LR sample + tables once
-        achieved = alg_k2 / (ms_stage[-1] * 1e-3) / 1e9
-        workload = "2-stage sdy x4, %d x LR %dx%dx3 -> HR %dx%dx3 per GPU per step, D-%s" % (
-            F, H, W, H * SCALE, W * SCALE, args.dist)
+        lut_bytes = 3 * 83521 * (1 + SCALE * SCALE)             # every table read once: SURVEY 8(d) LUT_bytes
+        alg = sites * (1 + SCALE * SCALE) + lut_bytes           # 17 B per LR sample + tables
+        alg_k2 = sites * (1 + SCALE * SCALE) + 3 * 83521 * SCALE * SCALE
+        workload = "2-stage sdy x4, %d x LR %dx%dx3 -> HR %dx%dx3 per GPU per step, D-%s" % (F, H, W, H * SCALE, W * SCALE, args.dist)
+        achieved = alg / (ms_step * 1e-3) / 1e9
+        k2_ms = float(ms_kernel[-1]) if ms_kernel[-1] > 0 else float(ms_stage[-1])
+        counters = load_profile_json("kernel_counters.json", workload if world == 1 else None) if world == 1 else None
+        traffic = load_profile_json("hbm_traffic.json", workload) if world == 1 else None
+        secondary = None
+        if counters:
+            k2 = counters["final_stage_kernel"]
+            secondary = {
+                "bound": "valu_issue", "kernel": k2["name"],
+                "achieved": round(k2["valu_wave_insts_per_launch"] / (k2_ms * 1e-3) / 1e9, 2),
+                "peak": round(SIMDS * CLOCK_GHZ / 4, 2), "unit": "G wave-instructions/s",
+                "frac": round(k2["valu_wave_insts_per_launch"] / (k2_ms * 1e-3) / 1e9 / (SIMDS * CLOCK_GHZ / 4), 4),
+                "how": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, profiles/kernel_counters.json, same source hash) / the kernel's "
+                       "event-timed duration in this run; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
+                "valu_insts_per_pass": round(k2["valu_wave_insts_per_launch"] / (sites / 64 * 12), 1),
+                "lds_gather": {"achieved": round(k2.get("lds_bytes_per_launch", 0) / (k2_ms * 1e-3) / 1e9, 1), "peak": round(LDS_PEAK_GBS, 1),
+                               "unit": "GB/s", "bytes_per_lr_sample": 12 * 5 * 32,
+                               "note": "row gathers of the final stage: 12 passes x 5 rows x 32 B (16-bit fields) per LR sample"},
+            }
         rec = {
             "metric": "Mpixels/sec SR-x4 2-stage sdy LUT inference (HR output pixels; LR-in = value/16)",
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strips else "weak",
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "frames_per_gpu": F, "lr": [H, W, 3], "stages": STAGES, "modes": MODES,
-                       "scale": SCALE, "luts": "shipped sr_x2sdy fine-tuned int8 tables", "parallelism":
-                       ("each frame cut into %d strips (+4-row halo), RCCL gather of the HR strips on rank 0" % world)
-                       if strips else ("frames sharded over %d GPU(s), no collective" % world),
+                       "scale": SCALE, "luts": "shipped sr_x2sdy fine-tuned int8 tables",
+                       "parallelism": "frames sharded over %d GPU(s), no collective" % world,
                        **{"value_D-%s" % k: round(v, 2) for k, v in others.items()}},
-            "roofline": {"bound": "hbm", "kernel": eng.kernel_name(True), "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": load_traffic(workload), "algorithmic_bytes_per_launch": alg_k2,
-                         "kernel_ms": round(float(ms_stage[-1]), 4),
+            "roofline": {"bound": "hbm", "kernel": "fused 2-stage pipeline: %s | %s" % (eng.kernel_name(False), eng.kernel_name(True)),
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic.get("pipeline_bytes_per_step") if traffic else None,
+                         "algorithmic_bytes_per_step": alg,
                          "stage_ms": [round(float(v), 4) for v in ms_stage],
-                         "pipeline_frac": round((alg_k2 + 3 * 83536) / (float(ms_stage.sum()) * 1e-3) / 1e9
-                                                / HBM_PEAK_GBS, 5)},
+                         "dominant_kernel": {"name": "stage_tube_kernel<rgb>" if "tube" in eng.kernel_name(True) else eng.kernel_name(True),
+                                             "ms": round(k2_ms, 4), "algorithmic_bytes_per_launch": alg_k2,
+                                             "achieved": round(alg_k2 / (k2_ms * 1e-3) / 1e9, 2),
+                                             "kernel_frac": round(alg_k2 / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                             "traffic": traffic.get("final_stage_bytes_per_launch") if traffic else None},
+                         "first_stage_kernel_ms": round(float(ms_kernel[0]), 4),
+                         "secondary": secondary},
         }
-        if world == 1 and args.cpu_crop > 0:
-            rec["cpu_baseline"] = cpu_baseline(eng, luts, host[0], min(args.cpu_crop, H, W))
+        if strips:
+            rec["config"]["strips_gather"] = strips
+        if cpu_rec is not None:
+            rec["cpu_baseline"] = cpu_rec
         print(json.dumps(rec))
     if dist_on:
         torch.distributed.destroy_process_group()
+
+
+def config3(args, eng, world, rank, dist_on, backend, timed):
+    """LR 2160x3840 batches (BASELINE config 3)."""
+    import torch
+    from mulut_amd.dist import sr_strips
+    Fs, Hs, Ws = args.strip_frames, 2160, 3840
+    steps = max(2, args.steps // 4)
+    frames = make_batch(args.dist, Fs, Hs, Ws, seed=0)                  # the same batch on every rank (host memory)
+    if world == 1:
+        x = torch.from_numpy(frames).cuda()
+        out = torch.empty((Fs, Hs * SCALE, Ws * SCALE, 3), dtype=torch.uint8, device="cuda")
+        eng.pipeline(x, out=out)
+        el = timed(lambda: eng.pipeline(x, out=out), steps)
+        return {"workload": "config 3 on one GPU: %d x LR %dx%dx3 whole frames per step" % (Fs, Hs, Ws), "n_gpus": 1,
+                "value": round(Fs * Hs * SCALE * Ws * SCALE * steps / el / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(el / steps * 1e3, 3)}
+    lr = torch.from_numpy(frames)
+    outs = [torch.empty((Fs, Hs * SCALE, Ws * SCALE, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None for _ in range(2)]
+    pend = [None, None]
+    via_host = backend != "nccl"
+
+    def compute(band, r0, y0, y1, hh):
+        return eng.pipeline_rows(band, r0, y0, y1, hh)
+
+    k = [0]
+
+    def step():
+        b = k[0] & 1
+        if pend[b] is not None:
+            pend[b].wait()                       # the gather issued two steps ago has landed: its buffer is free
+        pend[b] = sr_strips(lr, compute, SCALE, eng.halo, dst=0, out=outs[b], device="cuda", via_host=via_host, wait=False)
+        k[0] += 1
+
+    def drain():
+        for b in (0, 1):
+            if pend[b] is not None:
+                pend[b].wait()
+                pend[b] = None
+    step(); drain()
+    import time as _t
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    for _ in range(steps):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+    el = _t.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    el = float(t.item())
+    return {"workload": "config 3: %d x LR %dx%dx3 frames per step, each cut into %d strips (+%d-row halo); HR strips sent point to "
+                        "point into the frames on rank 0 (%s), the exchange of step k overlapping the compute of step k+1"
+                        % (Fs, Hs, Ws, world, eng.halo, "RCCL" if backend == "nccl" else backend + " via host memory"),
+            "n_gpus": world, "scaling": "strong", "value": round(Fs * Hs * SCALE * Ws * SCALE * steps / el / 1e6, 2), "unit": "Mpix/s",
+            "ms_per_step": round(el / steps * 1e3, 3), "gathered_bytes_per_step": Fs * Hs * SCALE * Ws * SCALE * 3 * (world - 1) // world}
+
+
+def config5(args, world, rank, local, timed):
+    """BASELINE config 5: 4-stage sdy x2 cascade on seeded synthetic tables, P1 input, eager launches vs one hipGraph replay."""
+    import torch
+    from mulut_amd import MuLUTEngine
+    stages, scale = 4, 2
+    rng = np.random.default_rng(5)
+    F, H, W = args.frames, args.lr_h, args.lr_w
+    eng = MuLUTEngine(local).configure(stages, MODES, scale, 4)
+    for s in range(1, stages + 1):
+        for m in MODES:
+            vn = scale * scale if s == stages else 1
+            base = rng.integers(-20, 21, (17, 17, 17, 17, vn)).astype(np.float32)
+            grid = np.indices((17, 17, 17, 17)).astype(np.float32).sum(0)[..., None] * (3.0 if s < stages else 4.0) - 96.0
+            eng.set_lut(s, m, np.clip(np.rint(grid + base), -127, 127).astype(np.int8).reshape(-1, vn))
+    eng.reserve(F, H, W, 3)
+    x = torch.from_numpy(make_batch(args.dist, F, H, W, seed=rank)).cuda()
+    out = torch.empty((F, H * scale, W * scale, 3), dtype=torch.uint8, device="cuda")
+    for _ in range(args.warmup):
+        eng.pipeline(x, out=out)
+    el_eager = timed(lambda: eng.pipeline(x, out=out), args.steps)
+    eng.set_stage_timing(True)
+    eng.pipeline(x, out=out)
+    ms_stage = eng.last_stage_ms()
+    eng.set_stage_timing(False)
+    want = out.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng.pipeline(x, out=out)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.pipeline(x, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(out, want))
+    el_graph = timed(g.replay, args.steps)
+    if rank == 0:
+        sites = F * H * W * 3
+        alg = sites * (1 + scale * scale) + 3 * 83521 * ((stages - 1) + scale * scale)
+        ms = el_graph / args.steps * 1e3
+        print(json.dumps({
+            "metric": "Mpixels/sec SR-x2 4-stage sdy LUT inference, hipGraph replay (HR output pixels)", "value": round(world * F * H * scale * W * scale * args.steps / el_graph / 1e6, 2),
+            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "config 5: 4-stage sdy x2, %d x LR %dx%dx3 -> HR %dx%dx3 per GPU per step, D-%s, seeded synthetic tables"
+                                   % (F, H, W, H * scale, W * scale, args.dist),
+                       "eager_ms_per_step": round(el_eager / args.steps * 1e3, 4), "graph_ms_per_step": round(ms, 4),
+                       "graph_replay_matches_eager": same, "stage_ms": [round(v, 4) for v in ms_stage],
+                       "kernels": [eng.kernel_name(False), eng.kernel_name(True)]},
+            "roofline": {"bound": "hbm", "kernel": "4-stage pipeline", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_step": alg},
+        }))
 
 
 if __name__ == "__main__":

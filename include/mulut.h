@@ -116,6 +116,10 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C);
  * each stage (n = number of stages written, <= cap).  Off by default (events cost a few us). */
 int mulut_set_stage_timing(mulut_ctx *ctx, int enable);
 int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap);
+/* The same call's milliseconds of each stage's DOMINANT kernel alone (the stage's helper launches -- tile statistic,
+ * fix-up lists, the kernel that takes the detailed tiles -- are in mulut_last_stage_ms only): the launch duration
+ * bench.py prices against the roofline. */
+int mulut_last_kernel_ms(mulut_ctx *ctx, float *ms, int cap);
 
 /* ---- LUT-aware fine-tuning (the differentiable twin; stateless, float32) -----------------------------
  * One stage of MuLUT.forward (sr/model.py:289-312) = InterpTorchBatch (:69-287) over all modes x 4 rotations
@@ -143,12 +147,20 @@ long long mulut_eval_ws_doubles(int H, int W);
 int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int W, int shave, double *ws, long long ws_doubles,
                  double *psnr, double *ssim, void *stream);
 
-/* Tuning knobs (never change results).  "final_stage_kernel": 0 = auto (hybrid when scale 4 and <= 3
- * modes), 1 = full-table gather kernel, 2 = compact LDS-band kernel, 3 = expanded LDS-band kernel, 4 = hybrid (a
- * per-tile statistic sends smooth 64x16 tiles to the band kernel and detailed ones to the full-table kernel).
- * "hybrid_oob_per_1024": tile threshold (sites out of band per 1024, default 128).  "first_stage_kernel" (stages with
- * 1-byte rows): 0 = window kernel (four adjacent pixels per thread, neighbours read as dwords), 1 = one LDS read per
- * neighbour.  Unknown key or value: MULUT_EINVAL. */
+/* Tuning knobs (never change results).
+ * "final_stage_kernel": 0 = auto (= 6 when scale 4 and <= 3 modes), 1 = full-table gather kernel, 2 = compact LDS-band
+ *   kernel, 3 = expanded LDS-band kernel (one mode resident), 4 = hybrid of 3 and 1, 5 = tube kernel (the bands of all modes
+ *   resident; pixels with a pass outside the tube are recomputed from the full table through a device work list), 6 = hybrid:
+ *   a per-tile statistic sends smooth 64x16 tiles to the tube kernel and detailed ones to the full-table kernel.
+ * "hybrid_oob_per_1024": tile threshold of the hybrids (sites out of band per 1024, default 128).
+ * "first_stage_kernel" (stages with 1-byte rows): 0 = auto (tube kernel; tiles its statistic calls detailed go to the
+ *   window kernel, flagged sites are recomputed through a device work list), 1 = one LDS read per neighbour, full table in
+ *   LDS, 2 = window kernel (full table in LDS), 3 = tube kernel on every tile.
+ * "first_stage_detail_per_1024": tile threshold of first_stage_kernel 0 (default 24).
+ * Unknown key or value: MULUT_EINVAL.
+ * hipGraph capture: call mulut_reserve() for the largest (N, H, W, C) first -- the context's workspace, verdict and work-list
+ * buffers are then never reallocated by smaller calls; a LARGER later call reallocates them and invalidates graphs captured
+ * before it. */
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value);
 
 /* Name of the kernel variant used for the final / non-final stage (for profiles). */

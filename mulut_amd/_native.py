@@ -16,7 +16,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 EXPORTS = [
     "mulut_version", "mulut_strerror", "mulut_last_hip_error", "mulut_create", "mulut_destroy",
     "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage", "mulut_pipeline",
-    "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing", "mulut_last_stage_ms",
+    "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing", "mulut_last_stage_ms", "mulut_last_kernel_ms",
     "mulut_set_tuning", "mulut_kernel_name", "mulut_ft_stage_forward", "mulut_ft_stage_backward",
     "mulut_eval_ws_doubles", "mulut_eval_y",
 ]
@@ -26,6 +26,17 @@ _libs = {}
 
 def _hipcc():
     return shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+
+
+def source_hash():
+    """sha256 over the kernel sources and headers: ties profiler-derived numbers (profiles/*.json) to the build they
+    were measured on -- bench.py reports them only while this hash still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(_CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def needs_build():
@@ -91,6 +102,7 @@ def load(path=None):
     L.mulut_reserve.argtypes = [p, i, i, i, i]
     L.mulut_set_stage_timing.argtypes = [p, i]
     L.mulut_last_stage_ms.argtypes = [p, ctypes.POINTER(ctypes.c_float), i]
+    L.mulut_last_kernel_ms.argtypes = [p, ctypes.POINTER(ctypes.c_float), i]
     L.mulut_set_tuning.argtypes = [p, c_char_p, i]
     L.mulut_kernel_name.argtypes = [p, i]
     L.mulut_ft_stage_forward.argtypes = [i, p, c_char_p, i, i, p, i, i, i, i, p, p]
@@ -103,7 +115,7 @@ def load(path=None):
     L.mulut_eval_y.restype = i
     for name in ("mulut_create", "mulut_destroy", "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage",
                  "mulut_pipeline", "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing",
-                 "mulut_last_stage_ms", "mulut_set_tuning", "mulut_ft_stage_forward", "mulut_ft_stage_backward"):
+                 "mulut_last_stage_ms", "mulut_last_kernel_ms", "mulut_set_tuning", "mulut_ft_stage_forward", "mulut_ft_stage_backward"):
         getattr(L, name).restype = i
     _libs[path] = L
     return L

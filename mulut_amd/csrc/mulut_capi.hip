@@ -55,6 +55,8 @@ struct mulut_ctx {
     int hybrid_oob_per_1024 = 128; // a tile is "detailed" when more than 1/8 of its (sampled) sites leave the band
     bool timing = false;
     hipEvent_t ev[MULUT_MAX_STAGES + 1] = {};
+    hipEvent_t evk[MULUT_MAX_STAGES][2] = {};   // around each stage's dominant kernel
+    bool evk_set[MULUT_MAX_STAGES] = {};
     int timed_stages = 0;
 };
 
@@ -129,6 +131,9 @@ int mulut_destroy(mulut_ctx *ctx) {
     if (ctx->tlist) (void)hipFree(ctx->tlist);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &p : ctx->evk)
+        for (auto &e : p)
+            if (e) (void)hipEventDestroy(e);
     delete ctx;
     return MULUT_OK;
 }
@@ -282,6 +287,17 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
     return MULUT_OK;
 }
 
+// bracket the dominant kernel of a stage with events when timing is on (mulut_last_kernel_ms)
+#define MAIN_KERNEL(ctx, stage, st, launch)                                                   \
+    do {                                                                                      \
+        if ((ctx)->timing) HIP_TRY(ctx, hipEventRecord((ctx)->evk[(stage) - 1][0], st));      \
+        HIP_TRY(ctx, launch);                                                                 \
+        if ((ctx)->timing) {                                                                  \
+            HIP_TRY(ctx, hipEventRecord((ctx)->evk[(stage) - 1][1], st));                      \
+            (ctx)->evk_set[(stage) - 1] = true;                                               \
+        }                                                                                     \
+    } while (0)
+
 static int stage_u(const mulut_ctx *ctx, int stage) { return stage == ctx->stages ? ctx->scale : 1; }
 
 // Tables of one stage in mode order, shape-checked against the stage's upscale.
@@ -378,7 +394,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         const bool tube1 = (ctx->first_kernel == 0 || ctx->first_kernel == 3) && ctx->n_modes <= 3 &&
                            (unsigned long long)N * C * H * W < (1ull << 32);
         if (!tube1) {
-            HIP_TRY(ctx, launch_stage_u1(a, st, ctx->first_kernel == 1 ? 1 : 0));
+            MAIN_KERNEL(ctx, stage, st, launch_stage_u1(a, st, ctx->first_kernel == 1 ? 1 : 0));
             return MULUT_OK;
         }
         // tube kernel on the smooth tiles; the sites it flags are recomputed from the full tables, the tiles it leaves go
@@ -397,7 +413,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.tile_count = ctx->tlist;
         a.tile_list = ctx->tlist + 16;
         a.verdict_take = route ? 0 : -1;
-        HIP_TRY(ctx, launch_stage_u1t(a, b1, (unsigned)ctx->u1_detail_per_1024, ctx->num_cus, st));
+        MAIN_KERNEL(ctx, stage, st, launch_stage_u1t(a, b1, (unsigned)ctx->u1_detail_per_1024, ctx->num_cus, st));
         if (route) HIP_TRY(ctx, launch_stage_u1w_list(a, ctx->num_cus, st));
         HIP_TRY(ctx, launch_stage_u1_fix(a, ctx->num_cus, st));
         return MULUT_OK;
@@ -406,7 +422,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || C == 1)) mode = kOutPlanarU4;
     else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3) mode = kOutPackedRGBU4;
     if (!band) {
-        HIP_TRY(ctx, launch_stage_up(a, u, mode, st));
+        MAIN_KERNEL(ctx, stage, st, launch_stage_up(a, u, mode, st));
         return MULUT_OK;
     }
     const bool x = ctx->final_kernel != 2;   // compact band only on request
@@ -433,8 +449,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.vt_x = a.tiles_x;
         a.vt_y = a.tiles_y;
         a.verdict_take = 0;
-        if (tube) HIP_TRY(ctx, launch_stage_tube(a, b, mode, ctx->num_cus, st));
-        else HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
+        if (tube) MAIN_KERNEL(ctx, stage, st, launch_stage_tube(a, b, mode, ctx->num_cus, st));
+        else MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
         StageArgs g = a;
         int gw, gh;
         stage_up_tile(gw, gh);
@@ -446,10 +462,10 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         return MULUT_OK;
     }
     if (tube) {
-        HIP_TRY(ctx, launch_stage_tube(a, b, mode, ctx->num_cus, st));
+        MAIN_KERNEL(ctx, stage, st, launch_stage_tube(a, b, mode, ctx->num_cus, st));
         HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
-    } else if (x) HIP_TRY(ctx, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
-    else HIP_TRY(ctx, launch_stage_band(a, b, mode, ctx->num_cus, st));
+    } else if (x) MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
+    else MAIN_KERNEL(ctx, stage, st, launch_stage_band(a, b, mode, ctx->num_cus, st));
     return MULUT_OK;
 }
 
@@ -588,9 +604,14 @@ int mulut_pipeline(mulut_ctx *ctx, const uint8_t *in, uint8_t *out, int N, int H
 int mulut_set_stage_timing(mulut_ctx *ctx, int enable) {
     if (!ctx) return MULUT_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (enable)
+    if (enable) {
         for (auto &e : ctx->ev)
             if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+        for (auto &p : ctx->evk)
+            for (auto &e : p)
+                if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+    }
+    for (auto &f : ctx->evk_set) f = false;
     ctx->timing = enable != 0;
     ctx->timed_stages = 0;
     return MULUT_OK;
@@ -601,6 +622,17 @@ int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap) {
     const int n = ctx->timed_stages < cap ? ctx->timed_stages : cap;
     if (n > 0) HIP_TRY(ctx, hipEventSynchronize(ctx->ev[ctx->timed_stages]));
     for (int s = 0; s < n; ++s) HIP_TRY(ctx, hipEventElapsedTime(&ms[s], ctx->ev[s], ctx->ev[s + 1]));
+    return n;
+}
+
+int mulut_last_kernel_ms(mulut_ctx *ctx, float *ms, int cap) {
+    if (!ctx || !ms || cap <= 0) return MULUT_EINVAL;
+    const int n = ctx->timed_stages < cap ? ctx->timed_stages : cap;
+    if (n > 0) HIP_TRY(ctx, hipEventSynchronize(ctx->ev[ctx->timed_stages]));
+    for (int s = 0; s < n; ++s) {
+        ms[s] = 0.0f;
+        if (ctx->evk_set[s]) HIP_TRY(ctx, hipEventElapsedTime(&ms[s], ctx->evk[s][0], ctx->evk[s][1]));
+    }
     return n;
 }
 

@@ -184,6 +184,14 @@ class MuLUTEngine:
             self._check(n)
         return [float(buf[k]) for k in range(n)]
 
+    def last_kernel_ms(self):
+        """Device milliseconds of each stage's dominant kernel alone in the last pipeline call (set_stage_timing(True))."""
+        buf = (ctypes.c_float * 8)()
+        n = self._lib.mulut_last_kernel_ms(self._h, buf, 8)
+        if n < 0:
+            self._check(n)
+        return [float(buf[k]) for k in range(n)]
+
     def eval_y(self, gt_hwc, out_hwc, shave):
         """(PSNR, SSIM) on the Y channel of two device uint8 HWC RGB images, as sr/4_test_lut.py:313-315 scores a result
         (common/utils.py:42-101) -- computed on the device, only two doubles come back."""

@@ -44,7 +44,15 @@ def _worker(rank, world, port, dst, shape, q):
     try:
         luts = _luts()
         img = torch.from_numpy(np.random.default_rng(7).integers(0, 256, shape, dtype=np.uint8))
-        out = sr_strips(img, _oracle_rows(luts), SCALE, HALO, dst=dst)
+        if img.dim() == 4:
+            # batched case: preallocated output + asynchronous handle (what bench.py's config-3 leg does)
+            shape_out = (shape[0], shape[1] * SCALE, shape[2] * SCALE, shape[3])
+            pre = torch.full(shape_out, 7, dtype=torch.uint8) if (dst is None or rank == dst) else None
+            pend = sr_strips(img, _oracle_rows(luts), SCALE, HALO, dst=dst, out=pre, wait=False)
+            out = pend.wait()
+            assert (out is pre) if pre is not None else (out is None)
+        else:
+            out = sr_strips(img, _oracle_rows(luts), SCALE, HALO, dst=dst)
         if dst is None or rank == dst:
             arr = img.numpy()
             want = np.stack([c_oracle.pipeline(luts, STAGES, MODES, SCALE, a) for a in (arr if arr.ndim == 4 else arr[None])])

@@ -371,3 +371,48 @@ def test_randomised_configurations_vs_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--cases", "60", "--seed", "123"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _strip_rank(rank, world, port, q):
+    """one rank of the config-3 rehearsal: real engine, strips + halo, gather on rank 0 (gloo moves host memory)"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mulut_amd import MuLUTEngine, load_lut_dict
+        from mulut_amd.dist import sr_strips
+        from mulut_amd.synth import natural_frames
+        luts = load_lut_dict(os.path.join(GOLDEN, "luts"), 2, "sdy", 4, 4, "LUT_ft")
+        eng = MuLUTEngine(0).configure(2, "sdy", 4, 4).set_lut_dict(luts)
+        frame = torch.from_numpy(natural_frames(1, 2160, 3840, 3, 3)[0])          # host memory, LR 2160 x 3840
+        frame[700:1500, 1000:2600] = torch.from_numpy(np.random.default_rng(4).integers(0, 256, (800, 1600, 3), dtype=np.uint8))
+        out = sr_strips(frame, lambda band, r0, y0, y1, hh: eng.pipeline_rows(band, r0, y0, y1, hh), 4, eng.halo, dst=0,
+                        device="cuda:0", via_host=True)
+        if rank == 0:
+            want = eng.pipeline(frame.cuda())
+            q.put((0, bool(torch.equal(out, want)), tuple(out.shape)))
+        else:
+            q.put((rank, out is None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config3_strips_on_4k_lr_frame_two_ranks():
+    """BASELINE config 3 at its real size: an LR 2160x3840 frame (smooth field with a block of noise, so both kernel
+    families of both stages run) cut into two strips (+4-row halo), one rank each (both on GPU 0, gloo), HR strips gathered
+    into the 8640x15360 frame on rank 0 == the single-GPU result, bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_strip_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got[0] == (0, True, (8640, 15360, 3)) and got[1][1]

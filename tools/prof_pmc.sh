@@ -23,7 +23,7 @@ PASSES=(
 )
 i=0
 for P in "${PASSES[@]}"; do
-  timeout -k 10 240 rocprofv3 --pmc $P --output-format csv -d "$OUT/p$i" -- python "$R/bench.py" --cpu-crop 0 --steps 2 --warmup 1 --skip-other "$@" > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/p$i.log"; }
+  timeout -k 10 240 rocprofv3 --pmc $P --output-format csv -d "$OUT/p$i" -- python "$R/bench.py" --cpu-crop 0 --steps 2 --warmup 1 --skip-other --skip-strips "$@" > "$OUT/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/p$i.log"; }
   i=$((i+1))
 done
 python "$R/tools/summarize_pmc.py" "$OUT" > "$OUT/summary.json" && cat "$OUT/summary.json"
