@@ -422,7 +422,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || C == 1)) mode = kOutPlanarU4;
     else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3) mode = kOutPackedRGBU4;
     if (!band) {
-        MAIN_KERNEL(ctx, stage, st, launch_stage_up(a, u, mode, st));
+        if (u == 4 && ctx->n_modes > 4) MAIN_KERNEL(ctx, stage, st, launch_stage_up_wide4(a, st));   // merged 16-bit fields hold 4 modes at most
+        else MAIN_KERNEL(ctx, stage, st, launch_stage_up(a, u, mode, st));
         return MULUT_OK;
     }
     const bool x = ctx->final_kernel != 2;   // compact band only on request

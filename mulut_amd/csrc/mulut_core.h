@@ -384,15 +384,18 @@ MULUT_HD constexpr int tube_slot(int A, int B, int C, int D) { return A * kTubeS
 // can keep the plane's LDS address within the 16-bit immediate of ds_read.  t_oob is zero in a half iff that
 // pass is in the tube (max - min of its four MSBs <= 1).
 struct TubePair {
-    uint32_t addr[5];   // byte offsets of the five rows inside a plane (+ bias), packed per pass
+    uint32_t base;      // byte offset of row 0 inside a plane (+ bias), packed per pass (row 4 = base + 16 * 65)
+    uint32_t step[3];   // byte strides of path steps 1..3, packed per pass (each < 4096)
     uint32_t w[5];      // weights, packed per pass
     uint32_t t_oob;
 };
-MULUT_HD void simplex4_tube_pair(uint32_t ca, uint32_t pb, uint32_t pc, uint32_t pd, uint32_t bias_pk, TubePair &o) {
-    constexpr uint32_t SA = kTubeSA * 16, SB = kTubeSB * 16, SC = kTubeSC * 16, SD = kTubeSD * 16;   // byte strides < 4096
-    const uint32_t ha16 = pk_dup(ca & 0xF0u);
+// anchor terms of a site, the same for every mode and rotation: the anchor's sort key and MSB term (16 h) in both halves
+MULUT_HD uint32_t tube_anchor_key(uint32_t ca) { return pk_dup((ca & 0xF000u) | (uint32_t)(kTubeSA * 16)); }
+MULUT_HD uint32_t tube_anchor_h16(uint32_t ca) { return pk_dup(ca & 0xF0u); }
+// base_a = ha16 * 27 + bias per half (bias: a multiple of 16 the caller keeps the plane's LDS address within reach with)
+MULUT_HD void simplex4_tube_pair(uint32_t k0, uint32_t ha16, uint32_t base_a, uint32_t pb, uint32_t pc, uint32_t pd, TubePair &o) {
+    constexpr uint32_t SB = kTubeSB * 16, SC = kTubeSC * 16, SD = kTubeSD * 16;   // byte strides < 4096
     const uint32_t hb16 = pb & 0x00F000F0u, hc16 = pc & 0x00F000F0u, hd16 = pd & 0x00F000F0u;     // 16*h per half
-    uint32_t k0 = pk_dup((ca & 0xF000u) | SA);
     uint32_t k1 = (pb & 0xF000F000u) | pk_dup(SB);
     uint32_t k2 = (pc & 0xF000F000u) | pk_dup(SC);
     uint32_t k3 = (pd & 0xF000F000u) | pk_dup(SD);
@@ -403,15 +406,12 @@ MULUT_HD void simplex4_tube_pair(uint32_t ca, uint32_t pb, uint32_t pc, uint32_t
     pk_cmpx_desc(k1, k2);
     const uint32_t f1 = pk_shr12(k0), f2 = pk_shr12(k1), f3 = pk_shr12(k2), f4 = pk_shr12(k3);
     // row offset in bytes = 16 * slot = (16 h) * slot stride, summed over the four keys
-    const uint32_t base = pk_mad(ha16, pk_dup(kTubeSA), pk_mad(hb16, pk_dup(kTubeSB), pk_mad(hc16, pk_dup(kTubeSC),
-                          pk_mad(hd16, pk_dup(kTubeSD), bias_pk))));
-    // plain 32-bit adds / subtracts from here on (full-rate VALU ops; the packed forms are half rate): no half
-    // ever carries or borrows -- offsets stay below 2^16, the sorted f's are descending, max >= min
-    o.addr[0] = base;
-    o.addr[1] = base + (k0 & 0x0FFF0FFFu);
-    o.addr[2] = o.addr[1] + (k1 & 0x0FFF0FFFu);
-    o.addr[3] = o.addr[2] + (k2 & 0x0FFF0FFFu);
-    o.addr[4] = base + pk_dup(kTubeAll * 16);     // (the kernels read row 4 through addr[0] and an immediate)
+    o.base = pk_mad(hb16, pk_dup(kTubeSB), pk_mad(hc16, pk_dup(kTubeSC), pk_mad(hd16, pk_dup(kTubeSD), base_a)));
+    o.step[0] = k0 & 0x0FFF0FFFu;
+    o.step[1] = k1 & 0x0FFF0FFFu;
+    o.step[2] = k2 & 0x0FFF0FFFu;
+    // plain 32-bit subtracts from here on (full-rate ops; the packed forms are half rate): no half ever borrows -- the
+    // sorted f's are descending, max >= min
     o.w[0] = pk_dup(kQ) - f1;
     o.w[1] = f1 - f2;
     o.w[2] = f2 - f3;
@@ -420,6 +420,11 @@ MULUT_HD void simplex4_tube_pair(uint32_t ca, uint32_t pb, uint32_t pc, uint32_t
     const uint32_t mx = pk_max(pk_max(hb16, hc16), pk_max(hd16, ha16));
     const uint32_t mn = pk_min(pk_min(hb16, hc16), pk_min(hd16, ha16));
     o.t_oob = (mx - mn) & 0xFFE0FFE0u;     // differences are multiples of 16: in the tube iff 0 or 16
+}
+// byte offsets of rows 0..3 of one pass (HALF 0 / 1) from the packed results
+MULUT_HD void tube_pair_rows(const TubePair &p, int half, uint32_t (&a)[4]) {
+    a[0] = half ? (p.base >> 16) : (p.base & 0xFFFFu);
+    for (int j = 0; j < 3; ++j) a[j + 1] = a[j] + (half ? (p.step[j] >> 16) : (p.step[j] & 0xFFFFu));
 }
 
 // The same pair math for tables with 1-byte rows (non-final stages): the tube band holds one dword per slot, so row

@@ -90,6 +90,8 @@ void stage_u1t_tile(int &tw, int &th);
 extern int g_u1t_persist;
 // final stage with u in {2,3,4}: u*u bytes out per site
 hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t st);
+// u == 4 and more than four modes (per-rotation accumulators)
+hipError_t launch_stage_up_wide4(const StageArgs &a, hipStream_t st);
 // final stage, u == 4, M <= 3: band tables resident in LDS, persistent workgroups
 hipError_t launch_stage_band(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 // same, with the band rows expanded to 16-bit fields in LDS (one mode resident, mode loop outermost)

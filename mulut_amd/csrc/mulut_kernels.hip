@@ -1002,8 +1002,11 @@ __device__ __forceinline__ void pk_mac(uint32_t &acc, uint32_t x, uint32_t wpk) 
 }
 
 // Per-rotation SWAR accumulators with compile-time names.  u == 4 merges rotation pairs (r, r+2)
-// into one accumulator each (mulut_core.h "merged rotation pairs"): 16 VGPRs instead of 32.
-template <int U>
+// into one accumulator each (mulut_core.h "merged rotation pairs"): 16 VGPRs instead of 32.  The merged form adds
+// all four rotations inside 16-bit fields (4 M 16 255 < 65536 only for M <= 4); with more modes u == 4 takes the
+// per-rotation form too (MERGED = false: a field holds one rotation, M 16 255 < 65536 for M <= 16, and sum() adds
+// the extracted fields in 32 bits).
+template <int U, bool MERGED = (U == 4)>
 struct RotAcc {
     static constexpr int RW = row_dwords(U);
     uint32_t lo0[RW], hi0[RW], lo1[RW], hi1[RW], lo2[RW], hi2[RW], lo3[RW], hi3[RW];
@@ -1028,7 +1031,7 @@ struct RotAcc {
 };
 
 template <>
-struct RotAcc<4> {
+struct RotAcc<4, true> {
     static constexpr int RW = 4;
     uint32_t lo02[4], hi02[4], lo13[4], hi13[4];
     __device__ __forceinline__ void clear() {
@@ -1193,9 +1196,9 @@ __device__ __forceinline__ void keep_rgb(int c, const uint32_t (&o)[U], uint32_t
 }
 
 // one pass against the full table in global memory
-template <int U, int R>
+template <int U, int R, class Acc>
 __device__ __forceinline__ void pass_global(const void *lut, int va, int vb, int vc, int vd, const StageArgs &a,
-                                            RotAcc<U> &acc) {
+                                            Acc &acc) {
     constexpr int RW = row_dwords(U);
     int idx[5], w[5];
     simplex4(va, vb, vc, vd, idx, w);
@@ -1220,7 +1223,7 @@ __device__ __forceinline__ void pass_global(const void *lut, int va, int vb, int
 // HY = false: one block per TW x TH tile.
 // HY = true (hybrid launch): four blocks per 64x16 verdict tile (its 2x2 sub-tiles); a block exits at once
 // unless the statistic marked the tile for this kernel (an empty block costs ~0.3 us of one CU).
-template <int U, int OUT, int TW, int TH, bool HY>
+template <int U, int OUT, int TW, int TH, bool HY, bool WIDE = false>
 __global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
     constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
     constexpr int NT = TW * TH;
@@ -1264,7 +1267,7 @@ __global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
     for (int c = 0; c < a.C; ++c) {
         const uint8_t *ctr = s_img + c * (PH * PW) + (ty + kHalo) * PW + (tx + kHalo);
         const int va = ctr[0];
-        RotAcc<U> acc;
+        RotAcc<U, (U == 4) && !WIDE> acc;
         acc.clear();
         for (int mv = 0; mv < a.M; ++mv) {
             // the mode index is wave-uniform: pin it to an SGPR so the per-mode kernel arguments
@@ -1331,6 +1334,16 @@ hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t 
         case 4: return launch_up<4, kOutGeneric>(a, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+// u == 4 with more than four modes: per-rotation accumulators (the merged ones would overflow their 16-bit fields)
+hipError_t launch_stage_up_wide4(const StageArgs &a, hipStream_t st) {
+    if (a.C > 3 || a.verdict_take >= 0) return hipErrorInvalidValue;
+    const size_t tile_bytes = ((3 * (size_t)(K2_TH + 2 * kHalo) * (K2_TW + 2 * kHalo) + 15) / 16) * 16;
+    const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;
+    if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((stage_up_kernel<4, kOutGeneric, K2_TW, K2_TH, false, true>), dim3((unsigned)nb), dim3(K2_TW * K2_TH), tile_bytes, st, a);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1814,26 +1827,39 @@ __device__ __forceinline__ void tube_mac_row(RotAcc<4> &acc, const uint4 &lo, co
     acc.template mac_x<R, HALF>(rlo, rhi, wpk);
 }
 
-// the five rows of one pass: all ten reads issued, then accumulated in order.  Row 4 (vertex 1111) sits a fixed
-// 65 slots after row 0: it shares row 0's address register and differs in the immediate only.
+// dst = a + (16-bit half SEL of b): one SDWA add extracts and adds
+template <int SEL>
+__device__ __forceinline__ uint32_t add_word(uint32_t a, uint32_t b) {
+    uint32_t r;
+    if constexpr (SEL == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// the five rows of one pass: all ten reads issued, then accumulated in order.  The byte offsets are built unpacked (one
+// SDWA add per row extracts the pass's half of the packed stride and adds it); row 4 (vertex 1111) sits a fixed 65
+// slots after row 0: it shares row 0's address register and differs in the immediate only.
 template <int R, int HALF, int IMM>
 __device__ __forceinline__ void tube_rows(const uint8_t *smem, const TubePair &bp, RotAcc<4> &acc) {
+    uint32_t a[4];
+    a[0] = HALF ? (bp.base >> 16) : (bp.base & 0xFFFFu);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[j + 1] = add_word<HALF>(a[j], bp.step[j]);
     uint4 lo[5], hi[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const uint32_t aj = bp.addr[j < 4 ? j : 0];
-        const uint32_t off = HALF ? (aj >> 16) : (aj & 0xFFFFu);
         constexpr int kRow4 = kTubeAll * 16;
-        lo[j] = *(const uint4 *)(smem + off + (IMM + (j < 4 ? 0 : kRow4)));
-        hi[j] = *(const uint4 *)(smem + off + (IMM + kTubePlaneBytes + (j < 4 ? 0 : kRow4)));
+        lo[j] = *(const uint4 *)(smem + a[j < 4 ? j : 0] + (IMM + (j < 4 ? 0 : kRow4)));
+        hi[j] = *(const uint4 *)(smem + a[j < 4 ? j : 0] + (IMM + kTubePlaneBytes + (j < 4 ? 0 : kRow4)));
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j) tube_mac_row<R, HALF>(acc, lo[j], hi[j], bp.w[j]);
 }
 
-// rotations R and R + 2 of one site and mode.  win = LDS byte address of the site's 5x5 window corner.
+// rotations R and R + 2 of one site and mode.  win = LDS byte address of the site's 5x5 window corner; k0 / ha16 / base_a:
+// the anchor's key, MSB term and slot term (+ this pattern's bias), hoisted by the caller.
 template <int PAT, int R, int PW>
-__device__ __forceinline__ void tube_pair(const uint8_t *smem, uint32_t win, uint32_t ca, RotAcc<4> &acc, uint32_t &dirty) {
+__device__ __forceinline__ void tube_pair(const uint8_t *smem, uint32_t win, uint32_t k0, uint32_t ha16, uint32_t base_a, RotAcc<4> &acc, uint32_t &dirty) {
     constexpr int IMM = PAT * kTubeBandBytes - tube_bias(PAT);
     static_assert(IMM >= 0 && IMM + kTubeAll * 16 + kTubePlaneBytes <= 65535 && tube_bias(PAT) + kTubePlaneBytes <= 65536 && tube_bias(PAT) % 16 == 0,
                   "ds_read immediate / packed offset range");
@@ -1846,7 +1872,7 @@ __device__ __forceinline__ void tube_pair(const uint8_t *smem, uint32_t win, uin
     const uint32_t pc = w[(2 + yc) * PW + 2 + xc] | ((uint32_t)w[(2 - yc) * PW + 2 - xc] << 16);
     const uint32_t pd = w[(2 + yd) * PW + 2 + xd] | ((uint32_t)w[(2 - yd) * PW + 2 - xd] << 16);
     TubePair bp;
-    simplex4_tube_pair(ca, pb, pc, pd, pk_dup((uint32_t)tube_bias(PAT)), bp);
+    simplex4_tube_pair(k0, ha16, base_a, pb, pc, pd, bp);
     // A pass outside the tube still walks the band (any key combination maps to a slot inside it, so the reads stay
     // in range) and adds garbage; the site is marked and recomputed from the full table by stage_up_fix_kernel.
     dirty |= bp.t_oob;
@@ -1855,9 +1881,10 @@ __device__ __forceinline__ void tube_pair(const uint8_t *smem, uint32_t win, uin
 }
 
 template <int PAT, int PW>
-__device__ __forceinline__ void tube_mode(const uint8_t *smem, uint32_t win, uint32_t ca, RotAcc<4> &acc, uint32_t &dirty) {
-    tube_pair<PAT, 0, PW>(smem, win, ca, acc, dirty);
-    tube_pair<PAT, 1, PW>(smem, win, ca, acc, dirty);
+__device__ __forceinline__ void tube_mode(const uint8_t *smem, uint32_t win, uint32_t k0, uint32_t ha16, uint32_t ha27, RotAcc<4> &acc, uint32_t &dirty) {
+    const uint32_t base_a = ha27 + pk_dup((uint32_t)tube_bias(PAT));
+    tube_pair<PAT, 0, PW>(smem, win, k0, ha16, base_a, acc, dirty);
+    tube_pair<PAT, 1, PW>(smem, win, k0, ha16, base_a, acc, dirty);
 }
 
 // Epilogue of one channel straight from the pair accumulators: the block value at (sy, sx) is the field of
@@ -1994,14 +2021,15 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
 #pragma clang loop unroll(disable)
             for (int c = 0; c < a.C; ++c, win += 2 * PH * PW) {
                 const uint32_t ca = *(const uint16_t *)(smem + win + 2 * (2 * PW + 2));
+                const uint32_t k0 = tube_anchor_key(ca), ha16 = tube_anchor_h16(ca), ha27 = pk_mad(ha16, pk_dup(kTubeSA), 0u);
                 RotAcc<4> acc;
                 acc.clear();
                 for (int mv = 0; mv < a.M; ++mv) {
                     const int m = __builtin_amdgcn_readfirstlane(mv);
                     const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;     // scalar
-                    if (pat == 0) tube_mode<0, PW>(smem, win, ca, acc, dirty);
-                    else if (pat == 1) tube_mode<1, PW>(smem, win, ca, acc, dirty);
-                    else tube_mode<2, PW>(smem, win, ca, acc, dirty);
+                    if (pat == 0) tube_mode<0, PW>(smem, win, k0, ha16, ha27, acc, dirty);
+                    else if (pat == 1) tube_mode<1, PW>(smem, win, k0, ha16, ha27, acc, dirty);
+                    else tube_mode<2, PW>(smem, win, k0, ha16, ha27, acc, dirty);
                 }
                 if constexpr (OUT == kOutPackedRGBU4) {
 #pragma unroll

@@ -51,7 +51,7 @@ static void stage_up(const int8_t *const *luts, const char *modes, int M, const 
                         for (int j = 0; j < 5; ++j) {
                             uint32_t row[RW];
                             for (int k = 0; k < RW; ++k) row[k] = tabs[m][(size_t)idx[j] * RW + k];
-                            if constexpr (U == 4) {
+                            if (U == 4 && M <= 4) {      // the kernels' dispatch: merged rotation pairs hold four modes at most
                                 uint32_t(&row4)[4] = reinterpret_cast<uint32_t(&)[4]>(row);
                                 if (r == 0) swar_fma<4>(lo02, hi02, row4, (uint32_t)w[j]);
                                 if (r == 1) swar_fma<4>(lo13, hi13, row4, (uint32_t)w[j]);
@@ -64,7 +64,7 @@ static void stage_up(const int8_t *const *luts, const char *modes, int M, const 
                     }
                 }
                 const int unbias = 128 * kQ * 4 * M - bias;
-                if constexpr (U == 4) {
+                if (U == 4 && M <= 4) {
                     uint32_t tl[4], th[4];
                     combine_pairs4(lo02, hi02, lo13, hi13, tl, th);
                     const float inv_d = 1.0f / (float)dv.d;
@@ -202,8 +202,10 @@ extern "C" long emul_check_tube_pair(int step) {
                     for (int vd = 0; vd < 256; vd += 1) {
                         const int vb2 = (vb * 7 + 3) & 255, vc2 = (vc * 5 + 11) & 255, vd2 = 255 - vd;
                         TubePair tp;
-                        simplex4_tube_pair(pixel_code(va), pixel_code(vb) | (pixel_code(vb2) << 16), pixel_code(vc) | (pixel_code(vc2) << 16),
-                                           pixel_code(vd) | (pixel_code(vd2) << 16), pk_dup(bias), tp);
+                        const uint32_t ca = pixel_code(va);
+                        simplex4_tube_pair(tube_anchor_key(ca), tube_anchor_h16(ca), pk_mad(tube_anchor_h16(ca), pk_dup(kTubeSA), pk_dup(bias)),
+                                           pixel_code(vb) | (pixel_code(vb2) << 16), pixel_code(vc) | (pixel_code(vc2) << 16),
+                                           pixel_code(vd) | (pixel_code(vd2) << 16), tp);
                         for (int half = 0; half < 2; ++half) {
                             const int b = half ? vb2 : vb, c = half ? vc2 : vc, d = half ? vd2 : vd;
                             int idx[5], w[5];
@@ -223,7 +225,11 @@ extern "C" long emul_check_tube_pair(int step) {
                                 if (in && !tube_contains(A, B, C, D)) ++bad;
                                 rows_s[j] = (uint32_t)tube_slot(A, B, C, D) * 16u + bias;
                                 wt_s[j] = w[j];
-                                rows_p[j] = half ? (tp.addr[j] >> 16) : (tp.addr[j] & 0xFFFFu);
+                                {
+                                    uint32_t ar[4];
+                                    tube_pair_rows(tp, half, ar);
+                                    rows_p[j] = j < 4 ? ar[j] : ar[0] + (uint32_t)(kTubeAll * 16);
+                                }
                                 wt_p[j] = wj;
                                 // in the tube or not, every offset the kernel would read lies inside the plane
                                 if (rows_p[j] < bias || rows_p[j] - bias > (uint32_t)(kTubePlaneBytes - 16) || (rows_p[j] & 15u)) ++bad;

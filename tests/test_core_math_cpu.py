@@ -73,6 +73,18 @@ def test_core_math_extreme_tables(emul):
         assert np.array_equal(run_emul(emul, l1, "sdy", False, img, 1), c_oracle.stage(l1, "sdy", False, img, 1))
 
 
+@pytest.mark.parametrize("modes", ["sdysd", "sdysdysd"])
+def test_core_math_many_modes_extreme_tables(emul, modes):
+    """u = 4 with more than four modes: the merged rotation-pair accumulators would overflow their 16-bit fields
+    (4 M 16 255 > 65535), so the per-rotation form is used -- all-(+127) / all-(-128) tables drive it to the limit"""
+    img = np.random.default_rng(9).integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    rng = np.random.default_rng(len(modes))
+    for val in (127, -128, None):
+        luts = [np.full((17 ** 4, 16), val, np.int8) if val is not None else rng.integers(-128, 128, (17 ** 4, 16), dtype=np.int8)
+                for _ in modes]
+        assert np.array_equal(run_emul(emul, luts, modes, True, img, 4), c_oracle.stage(luts, modes, True, img, 4)), (modes, val)
+
+
 def test_band_pair_index_math(emul):
     emul.emul_check_band_pair.restype = ctypes.c_long
     assert emul.emul_check_band_pair(5) == 0

@@ -373,6 +373,23 @@ def test_randomised_configurations_vs_oracle():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("modes", ["sdysd", "sdysdysd"])
+def test_more_than_four_modes_at_scale_4(modes):
+    """scale 4 with 5 and 8 modes: per-rotation accumulators (the merged pairs hold 4 x 16 x 255 per field at most),
+    extreme and random tables, vs the oracle"""
+    from mulut_amd import MuLUTEngine
+    rng = np.random.default_rng(len(modes))
+    img = rng.integers(0, 256, (2, 21, 34, 3), dtype=np.uint8)
+    for val in (127, -128, None):
+        luts = {"s1_%s" % m: (np.full((17 ** 4, 16), val, np.int8) if val is not None else rng.integers(-128, 128, (17 ** 4, 16), dtype=np.int8))
+                for m in set(modes)}
+        e = MuLUTEngine(0).configure(1, modes, 4, 4).set_lut_dict(luts)
+        got = e.pipeline(dev(img)).cpu().numpy()
+        want = np.stack([c_oracle.pipeline(luts, 1, modes, 4, im) for im in img])
+        assert np.array_equal(got, want), (modes, val)
+        e.close()
+
+
 def _strip_rank(rank, world, port, q):
     """one rank of the config-3 rehearsal: real engine, strips + halo, gather on rank 0 (gloo moves host memory)"""
     import torch.distributed as dist

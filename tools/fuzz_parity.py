@@ -47,7 +47,7 @@ def main():
     fails, done, px = [], 0, 0
     for case in range(args.cases):
         stages = int(rng.integers(1, 5))
-        modes = "".join(rng.choice(list("sdy"), int(rng.integers(1, 5))))
+        modes = "".join(rng.choice(list("sdy"), int(rng.integers(1, 9 if rng.random() < 0.2 else 5))))
         scale = int(rng.integers(1, 5))
         C = int(rng.integers(1, 4))
         h, w = int(rng.integers(1, 90)), int(rng.integers(1, 150))
