@@ -157,6 +157,8 @@ int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int
  *   window kernel, flagged sites are recomputed through a device work list), 1 = one LDS read per neighbour, full table in
  *   LDS, 2 = window kernel (full table in LDS), 3 = tube kernel on every tile.
  * "first_stage_detail_per_1024": tile threshold of first_stage_kernel 0 (default 24).
+ * "tube_site_flags": 1 = a separate pass (site_flag_kernel) marks the pixels whose 5x5 neighbourhood spans more than one MSB step and
+ *   the tube kernel drops its per-pass test; 0 (default) = per-pass tests.
  * Unknown key or value: MULUT_EINVAL.
  * hipGraph capture: call mulut_reserve() for the largest (N, H, W, C) first -- the context's workspace, verdict and work-list
  * buffers are then never reallocated by smaller calls; a LARGER later call reallocates them and invalidates graphs captured

@@ -46,6 +46,10 @@ struct mulut_ctx {
     size_t verdict_tiles = 0;
     uint32_t *fix = nullptr;       // [0] = count, [16...] = pixel ids of the tube kernel's fix-up list
     size_t fix_cap = 0;            // capacity in ids
+    uint8_t *sflags = nullptr;     // site_flag_kernel's byte per pixel of the final-stage input
+    size_t sflags_cap = 0;
+    int site_flags_on = 0;         // tuning "tube_site_flags": 1 = flags from site_flag_kernel (no per-pass test in the tube kernel: 4 % fewer
+                                   // cycles there, but the conservative 5x5 flags grow the fix-up list and the hybrid gains nothing), 0 = per-pass tests
     int first_kernel = 0;   // 1-byte-row stages: 0 auto (tube kernel, detailed tiles to the window kernel), 1 the original
                             // one-site-per-read kernel, 2 window kernel (full table in LDS), 3 tube kernel on every tile
     int u1_detail_per_1024 = 24;   // a tile goes to the full-table kernel when more than this share of its (sampled) 4-pixel groups spans > 1 MSB step
@@ -128,6 +132,7 @@ int mulut_destroy(mulut_ctx *ctx) {
         if (w) (void)hipFree(w);
     if (ctx->verdict) (void)hipFree(ctx->verdict);
     if (ctx->fix) (void)hipFree(ctx->fix);
+    if (ctx->sflags) (void)hipFree(ctx->sflags);
     if (ctx->tlist) (void)hipFree(ctx->tlist);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
@@ -355,6 +360,7 @@ static View make_view(const uint8_t *p, int layout, int rows, int W, int C, int 
 static int ensure_verdict(mulut_ctx *ctx, size_t tiles);
 static int ensure_fix(mulut_ctx *ctx, size_t ids);
 static int ensure_tlist(mulut_ctx *ctx, size_t tiles);
+static int ensure_sflags(mulut_ctx *ctx, size_t bytes);
 
 // Launch one stage: input view holds LR rows [in.row0, ...), outputs for LR rows [oy0, oy1).
 static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
@@ -435,6 +441,10 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.fix_count = ctx->fix;
         a.fix_list = ctx->fix + 16;
         HIP_TRY(ctx, hipMemsetAsync(ctx->fix, 0, sizeof(uint32_t), st));
+        if (ctx->site_flags_on) {
+            rc = ensure_sflags(ctx, (size_t)N * H * W);
+            if (rc) return rc;
+        }
     }
     BandArgs b;
     for (int m = 0; m < ctx->n_modes; ++m) {
@@ -445,7 +455,12 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         // per-tile choice on the device: smooth tiles -> LDS band kernel, detailed tiles -> full-table kernel
         rc = ensure_verdict(ctx, (size_t)N * a.tiles_x * a.tiles_y);
         if (rc) return rc;
-        HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st));
+        if (tube && ctx->site_flags_on) {
+            HIP_TRY(ctx, launch_site_flags(a, ctx->verdict, ctx->sflags, (uint32_t)ctx->hybrid_oob_per_1024, st));
+            a.site_flags = ctx->sflags;
+        } else {
+            HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st));
+        }
         a.verdict = ctx->verdict;
         a.vt_x = a.tiles_x;
         a.vt_y = a.tiles_y;
@@ -463,6 +478,10 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         return MULUT_OK;
     }
     if (tube) {
+        if (ctx->site_flags_on) {
+            HIP_TRY(ctx, launch_site_flags(a, nullptr, ctx->sflags, 0u, st));
+            a.site_flags = ctx->sflags;
+        }
         MAIN_KERNEL(ctx, stage, st, launch_stage_tube(a, b, mode, ctx->num_cus, st));
         HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
     } else if (x) MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
@@ -491,6 +510,16 @@ static int ensure_fix(mulut_ctx *ctx, size_t ids) {
     ctx->fix_cap = 0;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->fix, (ids + 16) * sizeof(uint32_t)));
     ctx->fix_cap = ids;
+    return MULUT_OK;
+}
+
+static int ensure_sflags(mulut_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->sflags_cap) return MULUT_OK;
+    if (ctx->sflags) HIP_TRY(ctx, hipFree(ctx->sflags));
+    ctx->sflags = nullptr;
+    ctx->sflags_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->sflags, bytes));
+    ctx->sflags_cap = bytes;
     return MULUT_OK;
 }
 
@@ -527,6 +556,10 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
             const bool u1 = ctx->stages > 1 || ctx->scale == 1;
             rc = ensure_fix(ctx, (size_t)N * H * W * (u1 ? (size_t)C : 1));
             if (rc) return rc;
+            if (ctx->scale == 4) {
+                rc = ensure_sflags(ctx, (size_t)N * H * W);
+                if (rc) return rc;
+            }
             if (u1) {
                 stage_u1_tile(tw, th);
                 rc = ensure_tlist(ctx, (size_t)N * ((W + tw - 1) / tw) * ((H + th - 1) / th));
@@ -647,6 +680,11 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "first_stage_kernel")) {
         if (value < 0 || value > 3) return MULUT_EINVAL;
         ctx->first_kernel = value;
+        return MULUT_OK;
+    }
+    if (!strcmp(key, "tube_site_flags")) {
+        if (value < 0 || value > 1) return MULUT_EINVAL;
+        ctx->site_flags_on = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "u1t_persist")) {      // experiment: persistent workgroups per CU of the 1-byte-row tube kernel (0 = one per tile)

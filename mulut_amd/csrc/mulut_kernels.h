@@ -51,6 +51,8 @@ struct StageArgs {
     // stage_up_fix_kernel; *fix_count is zeroed by the host side before the stage
     uint32_t *fix_list;
     uint32_t *fix_count;
+    // per-pixel flag bytes written by site_flag_kernel ahead of the tube kernel (null: the tube kernel tests every pass itself)
+    const uint8_t *site_flags;
     // 1-byte-row tube kernel: tile_list[tile] = 1 for the tiles it leaves to the full-table kernel (stage_u1w_kernel in
     // list mode); zeroed by the host side before the stage
     uint32_t *tile_list;
@@ -105,6 +107,8 @@ const char *stage_tube_name(int out_mode);
 hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st);
 // per-tile smooth/detailed verdict for the hybrid final stage (tiles of stage_band_tile())
 hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st);
+// per-pixel tube flags (bit c: channel c's 5x5 neighbourhood spans > 1 MSB step) + the same per-tile verdict from them
+hipError_t launch_site_flags(const StageArgs &a, uint32_t *verdict, uint8_t *flags, uint32_t max_per_1024, hipStream_t st);
 void stage_band_tile(int &tw, int &th);
 const char *stage_band_name(int out_mode);
 void stage_u1_tile(int &tw, int &th);

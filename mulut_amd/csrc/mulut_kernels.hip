@@ -964,6 +964,101 @@ __global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *v
 }
 
 // ------------------------------------------------------------------------------------------
+// Site flags for the tube kernel (and the hybrid's tile verdicts, replacing tile_stat_kernel on that path):
+// flags[(n H + y) W + x] bit c = the 5x5 neighbourhood of pixel (y, x) in channel c spans more than one MSB step,
+// i.e. one of the site's 12 passes may leave the tube.  MSBs are held as ONE-HOT 16-bit masks (1 << h), two pixels
+// per dword: the set of MSBs in a neighbourhood is then a plain OR -- separable, 5 columns then 5 rows -- and
+// "spans at most two adjacent values" is  M & ~(L | L << 1) == 0  with L = M & -M, all on packed halves.
+// One workgroup per 64x16 tile (the tube kernel's tile); verdict[tile] = 1 when more than max_per_1024 of its
+// pixels are flagged.
+// LDS: [ one-hot tile 3 x 20 x 68 u16 ][ horizontal ORs 3 x 20 x 64 u16 ]
+// ------------------------------------------------------------------------------------------
+template <int TW, int TH>
+__global__ void __launch_bounds__(256) site_flag_kernel(StageArgs a, uint32_t *verdict, uint8_t *flags, uint32_t max_per_1024) {
+    constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo, NT = 256;
+    __shared__ __attribute__((aligned(16))) uint16_t s_oh[3 * PH * PW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_hr[3 * PH * TW];
+    __shared__ uint32_t s_cnt, s_valid;
+    int n, y0, x0;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    decode_tile(a, id, n, y0, x0, TW, TH);
+    if (threadIdx.x == 0) { s_cnt = 0; s_valid = 0; }
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    const bool planar = a.in.sX == 1 && ((a.W | a.in.sY | a.in.sC) & 3) == 0 && (a.in.sN & 3) == 0 && (((uintptr_t)a.in.p) & 3) == 0;
+    if (planar) {
+        constexpr int GR = (TW + 8) / 4;            // aligned dwords cover image columns x0-4 .. x0+67
+        for (int i = threadIdx.x; i < a.C * PH * GR; i += NT) {
+            const int g = i % GR, row = (i / GR) % PH, c = i / (GR * PH);
+            const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
+            const int gx = x0 - 4 + 4 * g, cgx = imin(imax(gx, 0), a.W - 4);
+            uint32_t d = *(const uint32_t *)view_addr(a.in, n, c, gy, cgx);
+            if (gx < 0) d = (d & 0xFFu) * 0x01010101u;                  // left of the image: column 0
+            else if (gx > a.W - 4) d = (d >> 24) * 0x01010101u;          // right of it: column W-1
+            const uint32_t p01 = (1u << ((d >> 4) & 15u)) | (0x10000u << ((d >> 12) & 15u));
+            const uint32_t p23 = (1u << ((d >> 20) & 15u)) | (0x10000u << (d >> 28));
+            uint32_t *dst = (uint32_t *)(s_oh + (c * PH + row) * PW + 4 * g - 2);      // tile columns 4g-2 .. 4g+1
+            if (g > 0) dst[0] = p01;
+            if (4 * g + 1 < PW) dst[1] = p23;
+        }
+    } else {
+        for (int i = threadIdx.x; i < a.C * PH * PW; i += NT) {
+            const int px = i % PW, row = (i / PW) % PH, c = i / (PW * PH);
+            const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
+            const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
+            s_oh[i] = (uint16_t)(1u << (*view_addr(a.in, n, c, gy, gx) >> 4));
+        }
+    }
+    __syncthreads();
+    // columns: pixel pair (x, x+1), x even, takes tile columns x .. x+5 = three dwords
+    for (int i = threadIdx.x; i < a.C * PH * (TW / 2); i += NT) {
+        const int xp = i % (TW / 2), row = (i / (TW / 2)) % PH, c = i / ((TW / 2) * PH);
+        const uint32_t *src = (const uint32_t *)(s_oh + (c * PH + row) * PW) + xp;
+        const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+        const uint32_t mid = d1 | __builtin_amdgcn_alignbit(d1, d1, 16);            // columns x+2, x+3 in both halves
+        const uint32_t e = __builtin_amdgcn_perm(d2, d0, 0x05040302u);              // low half: column x+1, high half: column x+4
+        const uint32_t common = mid | e | __builtin_amdgcn_alignbit(e, e, 16);      // columns x+1 .. x+4 in both halves
+        ((uint32_t *)(s_hr + (c * PH + row) * TW))[xp] = common | (d0 & 0x0000FFFFu) | (d2 & 0xFFFF0000u);
+    }
+    __syncthreads();
+    // rows, test, flag bytes of two pixels at once
+    uint32_t bad = 0, valid = 0;
+    for (int i = threadIdx.x; i < TH * (TW / 2); i += NT) {
+        const int xp = i % (TW / 2), ty = i / (TW / 2);
+        const int y = y0 + ty, x = x0 + 2 * xp;
+        if (y >= a.oy1 || x >= a.W) continue;
+        uint32_t fl = 0;
+        for (int c = 0; c < a.C; ++c) {
+            const uint32_t *col = (const uint32_t *)(s_hr + (c * PH + ty) * TW) + xp;
+            const uint32_t m = col[0] | col[TW / 2] | col[2 * (TW / 2)] | col[3 * (TW / 2)] | col[4 * (TW / 2)];
+            const uint32_t low = m & pk_sub(0u, m);                                  // lowest set bit per half
+            const uint32_t two = low | ((low << 1) & 0xFFFEFFFEu);                   // it and its upper neighbour
+            const uint32_t out = m & ~two;
+            fl |= (((out & 0xFFFFu) ? 1u : 0u) | ((out >> 16) ? 0x100u : 0u)) << c;
+        }
+        uint8_t *dst = flags + ((size_t)n * a.H + y) * a.W + x;
+        dst[0] = (uint8_t)fl;
+        bad += (fl & 0xFFu) ? 1u : 0u;
+        valid += 1;
+        if (x + 1 < a.W) {
+            dst[1] = (uint8_t)(fl >> 8);
+            bad += (fl >> 8) ? 1u : 0u;
+            valid += 1;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { bad += __shfl_down(bad, o); valid += __shfl_down(valid, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt, bad); atomicAdd(&s_valid, valid); }
+    __syncthreads();
+    if (threadIdx.x == 0 && verdict) verdict[id] = (s_cnt * 1024u > max_per_1024 * s_valid) ? 1u : 0u;   // 1 = detailed
+}
+
+hipError_t launch_site_flags(const StageArgs &a, uint32_t *verdict, uint8_t *flags, uint32_t max_per_1024, hipStream_t st) {
+    const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;   // a.tiles_* must be the 64x16 tiling
+    if (nb <= 0 || nb > 0x7fffffffLL || a.C > 3 || !flags) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((site_flag_kernel<64, 16>), dim3((unsigned)nb), dim3(256), 0, st, a, verdict, flags, max_per_1024);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // K2: final stage, u*u-byte rows.
 // One thread = one LR pixel, channels in sequence.  Per rotation the 5*M weighted rows are
 // accumulated as 16-bit fields, two per dword:  lo[k] holds row elements 4k and 4k+2, hi[k] holds
@@ -1858,7 +1953,7 @@ __device__ __forceinline__ void tube_rows(const uint8_t *smem, const TubePair &b
 
 // rotations R and R + 2 of one site and mode.  win = LDS byte address of the site's 5x5 window corner; k0 / ha16 / base_a:
 // the anchor's key, MSB term and slot term (+ this pattern's bias), hoisted by the caller.
-template <int PAT, int R, int PW>
+template <int PAT, int R, int PW, bool FLAGGED>
 __device__ __forceinline__ void tube_pair(const uint8_t *smem, uint32_t win, uint32_t k0, uint32_t ha16, uint32_t base_a, RotAcc<4> &acc, uint32_t &dirty) {
     constexpr int IMM = PAT * kTubeBandBytes - tube_bias(PAT);
     static_assert(IMM >= 0 && IMM + kTubeAll * 16 + kTubePlaneBytes <= 65535 && tube_bias(PAT) + kTubePlaneBytes <= 65536 && tube_bias(PAT) % 16 == 0,
@@ -1872,19 +1967,20 @@ __device__ __forceinline__ void tube_pair(const uint8_t *smem, uint32_t win, uin
     const uint32_t pc = w[(2 + yc) * PW + 2 + xc] | ((uint32_t)w[(2 - yc) * PW + 2 - xc] << 16);
     const uint32_t pd = w[(2 + yd) * PW + 2 + xd] | ((uint32_t)w[(2 - yd) * PW + 2 - xd] << 16);
     TubePair bp;
-    simplex4_tube_pair(k0, ha16, base_a, pb, pc, pd, bp);
+    simplex4_tube_pair<FLAGGED>(k0, ha16, base_a, pb, pc, pd, bp);
     // A pass outside the tube still walks the band (any key combination maps to a slot inside it, so the reads stay
-    // in range) and adds garbage; the site is marked and recomputed from the full table by stage_up_fix_kernel.
-    dirty |= bp.t_oob;
+    // in range) and adds garbage; the site is marked -- by site_flag_kernel ahead of this launch (FLAGGED), else by the
+    // per-pass test here -- and recomputed from the full table by stage_up_fix_kernel.
+    if constexpr (!FLAGGED) dirty |= bp.t_oob;
     tube_rows<R, 0, IMM>(smem, bp, acc);
     tube_rows<R + 2, 1, IMM>(smem, bp, acc);
 }
 
-template <int PAT, int PW>
+template <int PAT, int PW, bool FLAGGED>
 __device__ __forceinline__ void tube_mode(const uint8_t *smem, uint32_t win, uint32_t k0, uint32_t ha16, uint32_t ha27, RotAcc<4> &acc, uint32_t &dirty) {
     const uint32_t base_a = ha27 + pk_dup((uint32_t)tube_bias(PAT));
-    tube_pair<PAT, 0, PW>(smem, win, k0, ha16, base_a, acc, dirty);
-    tube_pair<PAT, 1, PW>(smem, win, k0, ha16, base_a, acc, dirty);
+    tube_pair<PAT, 0, PW, FLAGGED>(smem, win, k0, ha16, base_a, acc, dirty);
+    tube_pair<PAT, 1, PW, FLAGGED>(smem, win, k0, ha16, base_a, acc, dirty);
 }
 
 // Epilogue of one channel straight from the pair accumulators: the block value at (sy, sx) is the field of
@@ -1912,7 +2008,7 @@ __device__ __forceinline__ void tube_finish_rows(const StageArgs &a, RotAcc<4> &
     }
 }
 
-template <int OUT, int TW, int TH>
+template <int OUT, int TW, int TH, bool FLAGGED>
 __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArgs b) {
     constexpr int PW = TW + 2 * kTubeHaloX, PH = TH + 2 * kHalo;     // tile image: columns x0-4 .. x0+TW+3, rows y0-2 .. y0+TH+1
     constexpr int NT = TW * TH;
@@ -2017,7 +2113,8 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
             uint32_t o0[4], o1[4], o2[4];     // packed output rows of the finished channels (RGB path)
 #pragma unroll
             for (int k = 0; k < 4; ++k) o0[k] = o1[k] = o2[k] = 0;
-            uint32_t dirty = 0;               // != 0: some pass of this pixel left the tube
+            // != 0: some pass of this pixel may have left the tube (FLAGGED: site_flag_kernel's byte for the pixel)
+            uint32_t dirty = FLAGGED ? (uint32_t)a.site_flags[((size_t)n * a.H + y) * a.W + x] : 0u;
 #pragma clang loop unroll(disable)
             for (int c = 0; c < a.C; ++c, win += 2 * PH * PW) {
                 const uint32_t ca = *(const uint16_t *)(smem + win + 2 * (2 * PW + 2));
@@ -2027,9 +2124,9 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
                 for (int mv = 0; mv < a.M; ++mv) {
                     const int m = __builtin_amdgcn_readfirstlane(mv);
                     const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;     // scalar
-                    if (pat == 0) tube_mode<0, PW>(smem, win, k0, ha16, ha27, acc, dirty);
-                    else if (pat == 1) tube_mode<1, PW>(smem, win, k0, ha16, ha27, acc, dirty);
-                    else tube_mode<2, PW>(smem, win, k0, ha16, ha27, acc, dirty);
+                    if (pat == 0) tube_mode<0, PW, FLAGGED>(smem, win, k0, ha16, ha27, acc, dirty);
+                    else if (pat == 1) tube_mode<1, PW, FLAGGED>(smem, win, k0, ha16, ha27, acc, dirty);
+                    else tube_mode<2, PW, FLAGGED>(smem, win, k0, ha16, ha27, acc, dirty);
                 }
                 if constexpr (OUT == kOutPackedRGBU4) {
 #pragma unroll
@@ -2118,14 +2215,16 @@ const char *stage_tube_name(int out_mode) {
 
 template <int OUT>
 static hipError_t launch_tube_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
-    auto kern = stage_tube_kernel<OUT, KB_TW, KB_TH>;
-    static bool attr_set[64] = {};
+    auto kern_t = stage_tube_kernel<OUT, KB_TW, KB_TH, true>;
+    auto kern_f = stage_tube_kernel<OUT, KB_TW, KB_TH, false>;
+    auto kern = a.site_flags ? kern_t : kern_f;
+    static bool attr_set[64][2] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev][a.site_flags ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev][a.site_flags ? 1 : 0] = true;
     }
     const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
