@@ -3,7 +3,7 @@
 Deviations, both documented in DESIGN.md:
   * ``parse()`` does not copy every ``*.py`` under cwd into ``<expDir>/code`` (common/option.py:104-110,155-156);
     pass ``--saveCode`` to get that side effect back.  ``--debug`` is accepted and means what it meant.
-  * new optional flags (``--device``, ``--datasets``, ``--batch``) default to the reference's behaviour.
+  * new optional flags (``--device``, ``--datasets``, ``--batch``, ``--ioWorkers``, ``--timing``) default to the reference's behaviour.
 """
 import argparse
 import os
@@ -39,6 +39,9 @@ class TestOptions:
         parser.add_argument('--datasets', type=str, default='Set5', help="comma separated (reference: ['Set5'])")
         parser.add_argument('--deviceMetrics', action='store_true', default=False,
                             help="score PSNR/SSIM on the GPU (same numbers; saves the host-side SciPy convolutions)")
+        parser.add_argument('--ioWorkers', type=int, default=4,
+                            help='PNG decode threads ahead of the GPU and encode / score threads behind it (1 = strictly serial)')
+        parser.add_argument('--timing', action='store_true', default=False, help='also print end-to-end images/s per dataset')
         parser.add_argument('--saveCode', action='store_true', default=False,
                             help="copy *.py under cwd into <expDir>/code like the reference's parse()")
         return parser

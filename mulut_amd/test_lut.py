@@ -38,7 +38,34 @@ class eltr:
         self.engine = engine
 
     def run(self, num_worker=None):
-        psnr_ssim_s = [self._worker(i) for i in range(len(self.files))]
+        """The reference maps `_worker` over the files with Pool(24) (:257-259).  Here the GPU does the cascade, so the
+        host work is what is left to overlap: `num_worker` threads decode the PNG pairs ahead of the GPU and another
+        `num_worker` encode / score finished images behind it (PIL and zlib release the GIL), while the main thread feeds
+        the device.  num_worker <= 1 runs the files strictly one after the other."""
+        import time
+        nw = int(num_worker if num_worker is not None else getattr(self.opt, "ioWorkers", 4))
+        t0 = time.perf_counter()
+        if nw <= 1 or len(self.files) < 2:
+            psnr_ssim_s = [self._worker(i) for i in range(len(self.files))]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(nw) as dec, ThreadPoolExecutor(nw) as enc:
+                loads = [dec.submit(self._load, i) for i in range(len(self.files))]
+                done = []
+                for i, fut in enumerate(loads):
+                    img_lr, img_gt = fut.result()
+                    dev_out = self.super_resolve_device(img_lr)
+                    if self.device_metrics:
+                        gt = torch.from_numpy(np.ascontiguousarray(img_gt)).to(self.engine.device)
+                        score = list(self.engine.eval_y(gt, dev_out, self.opt.scale))
+                        done.append(enc.submit(self._finish, i, dev_out.cpu().numpy(), None, score))
+                    else:
+                        done.append(enc.submit(self._finish, i, dev_out.cpu().numpy(), img_gt, None))
+                psnr_ssim_s = [f.result() for f in done]
+        self.seconds = time.perf_counter() - t0
+        if getattr(self.opt, "timing", False):
+            print('Dataset {} | {} images in {:.2f} s end to end ({:.2f} images/s, {} I/O threads each way)'.format(
+                self.dataset, len(self.files), self.seconds, len(self.files) / max(self.seconds, 1e-9), nw))
         arr = np.asarray(psnr_ssim_s)
         print('Dataset {} | AVG LUT PSNR: {:.2f} SSIM: {:.4f}'.format(self.dataset, np.mean(arr[:, 0]),
                                                                       np.mean(arr[:, 1])))
@@ -54,7 +81,8 @@ class eltr:
     def super_resolve(self, img_lr):
         return self.super_resolve_device(img_lr).cpu().numpy()
 
-    def _worker(self, i):
+    def _load(self, i):
+        """decode the LR / HR pair of file i (:265-277)"""
         opt = self.opt
         img_lr = np.array(Image.open(
             os.path.join(opt.testDir, self.dataset, 'LR_bicubic/X{}'.format(opt.scale), self.files[i])))
@@ -62,16 +90,26 @@ class eltr:
         img_gt = modcrop(img_gt, opt.scale)
         if img_gt.ndim == 2:
             img_gt = np.stack([img_gt] * 3, axis=2)
-        dev_out = self.super_resolve_device(img_lr)
-        img_out = dev_out.cpu().numpy()
+        return img_lr, img_gt
+
+    def _finish(self, i, img_out, img_gt, score):
+        """save the result (:309-312) and, unless the device scored it already, compute Y-PSNR / SSIM on the host (:313-316)"""
+        opt = self.opt
         Image.fromarray(img_out).save(os.path.join(
             self.result_path, '{}_{}_{}bit.png'.format(self.files[i].split('/')[-1][:-4], opt.lutName,
                                                        8 - opt.interval)))
-        if self.device_metrics:
-            gt = torch.from_numpy(np.ascontiguousarray(img_gt)).to(self.engine.device)
-            return list(self.engine.eval_y(gt, dev_out, opt.scale))
+        if score is not None:
+            return score
         y_gt, y_out = rgb2ycbcr(img_gt)[:, :, 0], rgb2ycbcr(img_out)[:, :, 0]
         return [psnr(y_gt, y_out, opt.scale), ssim(y_gt, y_out)]
+
+    def _worker(self, i):
+        img_lr, img_gt = self._load(i)
+        dev_out = self.super_resolve_device(img_lr)
+        if self.device_metrics:
+            gt = torch.from_numpy(np.ascontiguousarray(img_gt)).to(self.engine.device)
+            return self._finish(i, dev_out.cpu().numpy(), None, list(self.engine.eval_y(gt, dev_out, self.opt.scale)))
+        return self._finish(i, dev_out.cpu().numpy(), img_gt, None)
 
 
 def build_engine(opt):

@@ -98,10 +98,15 @@ def test_finetune_driver_reduces_loss_and_writes_luts(tmp_path):
             rng = np.random.default_rng(s * 7 + ord(m))
             noisy = np.clip(t.astype(np.int32) + rng.integers(-12, 13, t.shape), -127, 127).astype(np.int8)
             np.save(exp / ("LUT_x4_4bit_int8_s%d_%s.npy" % (s, m)), noisy)
+    val_root = str(tmp_path / "bench")                       # {valDir}/Set5/{HR, LR_bicubic/X4}
+    os.makedirs(val_root)
+    os.symlink(os.path.join(GOLDEN, "Set5"), os.path.join(val_root, "Set5"))
     losses = finetune_lut.main(["--stages", "2", "--modes", "sdy", "-e", str(exp), "--trainDir", os.path.join(GOLDEN, "Set5"),
                                 "--batchSize", "16", "--cropSize", "24", "--totalIter", "60", "--displayStep", "20",
-                                "--lr0", "1e-3", "--seed", "0"])
+                                "--lr0", "1e-3", "--seed", "0", "--valDir", val_root, "--valStep", "60"])
     assert np.mean(losses[-15:]) < np.mean(losses[:15])
+    # validation loop (sr/3_finetune_lut.py:23-65): at iterations 1 and 60 every Set5 image was scored and saved
+    assert sorted(os.listdir(os.path.join(str(exp), "val", "Set5"))) == sorted(f[:-4] + "_lutft.png" for f in os.listdir(os.path.join(GOLDEN, "Set5", "HR")))
     luts = load_lut_dict(str(exp), 2, "sdy", 4, 4, "LUT_ft")
     assert luts["s2_y"].dtype == np.int8 and luts["s2_y"].shape == (83521, 16)
     eng = MuLUTEngine(0).configure(2, "sdy", 4, 4).set_lut_dict(luts)
