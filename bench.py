@@ -166,8 +166,9 @@ def main():
     ap.add_argument("--skip-other", action="store_true", help="do not also time the other input distributions")
     ap.add_argument("--skip-strips", action="store_true", help="N > 1: do not also time the strips + gather sharding (config 3)")
     ap.add_argument("--strip-frames", type=int, default=4, help="LR 2160x3840 frames per step of the strips + gather leg")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 5],
-                    help="2: headline (2-stage sdy x4); 5: deep cascade (4-stage sdy x2, seeded synthetic tables), eager vs hipGraph")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
+                    help="2: headline (2-stage sdy x4); 4: LUT fine-tune step (fwd + bwd + Adam, bs 256 x 1x48x48); "
+                         "5: deep cascade (4-stage sdy x2, seeded synthetic tables), eager vs hipGraph")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -223,6 +224,8 @@ def main():
 
     if args.config == 5:
         return config5(args, world, rank, local, timed)
+    if args.config == 4:
+        return config4(args, world, rank, local, timed)
 
     eng = MuLUTEngine(local).configure(STAGES, MODES, SCALE, 4).set_lut_dict(luts)
     eng.reserve(F, H, W, 3)
@@ -381,6 +384,44 @@ def config3(args, eng, world, rank, dist_on, backend, timed):
                         % (Fs, Hs, Ws, world, eng.halo, "RCCL" if backend == "nccl" else backend + " via host memory"),
             "n_gpus": world, "scaling": "strong", "value": round(Fs * Hs * SCALE * Ws * SCALE * steps / el / 1e6, 2), "unit": "Mpix/s",
             "ms_per_step": round(el / steps * 1e3, 3), "gathered_bytes_per_step": Fs * Hs * SCALE * Ws * SCALE * 3 * (world - 1) // world}
+
+
+def config4(args, world, rank, local, timed):
+    """BASELINE config 4: one LUT fine-tune step (forward + backward HIP kernels + Adam) at bs 256 of 1x48x48 crops, 2-stage sdy x4."""
+    import tempfile
+    import torch
+    from mulut_amd.finetune import MuLUT
+    from mulut_amd.synth import natural_frames
+    bs, crop = 256, 48
+    with tempfile.TemporaryDirectory() as td:
+        for s_ in (1, 2):
+            for m in MODES:
+                np.save(os.path.join(td, "LUT_x4_4bit_int8_s%d_%s.npy" % (s_, m)), np.load(os.path.join(LUT_DIR, "LUT_ft_x4_4bit_int8_s%d_%s.npy" % (s_, m))))
+        net = MuLUT(td, 2, MODES, upscale=4, interval=4).cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    big = natural_frames(1, 1080, 1920, 1, rank)[0, :, :, 0]
+    rng = np.random.default_rng(rank)
+    ys, xs = rng.integers(0, 1080 - crop, bs), rng.integers(0, 1920 - crop, bs)
+    x = torch.from_numpy(np.stack([big[a:a + crop, b:b + crop] for a, b in zip(ys, xs)])[:, None].astype(np.float32) / 255.0).cuda()
+    y = torch.rand((bs, 1, crop * 4, crop * 4), device="cuda", generator=torch.Generator(device="cuda").manual_seed(rank))
+
+    def step():
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(net(x), y).backward()
+        opt.step()
+    for _ in range(max(args.warmup, 3)):
+        step()
+    el = timed(step, args.steps)
+    if rank == 0:
+        ms = el / args.steps * 1e3
+        print(json.dumps({
+            "metric": "LR Mpixels/sec through one LUT fine-tune step (forward + backward + Adam), 2-stage sdy x4", "value": round(world * bs * crop * crop * args.steps / el / 1e6, 3),
+            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config 4: bs 256 x 1x48x48 crops of the D-natural field per GPU per step, shipped tables as the start point",
+                       "note": "replicas only: each rank trains its own copy (a data-parallel all-reduce of the six table gradients is not built)",
+                       "reference_logged": "7.0 s/iter at batch 320 (models/sr_x2sdy/lutft.log), unspecified 2022 GPU"},
+        }))
 
 
 def config5(args, world, rank, local, timed):

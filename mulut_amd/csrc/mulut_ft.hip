@@ -58,6 +58,8 @@ struct FtPass {
     int idx[5];      // table rows of the five vertices
     float wt[5];     // q-f1, f1-f2, f2-f3, f3-f4, f4
     int src[4];      // flat pixel index (within the channel plane) of the key of rank j
+    int tslot[5];    // tube-band slots of the five vertices (mulut_core.h), valid when in_tube
+    bool in_tube;    // the four MSBs span at most one step: every vertex lies in the 1041-slot tube band
 };
 
 __device__ __forceinline__ void ft_pass_setup(const float *plane, int H, int W, int y, int x, int r, const int (&di)[3],
@@ -91,6 +93,22 @@ __device__ __forceinline__ void ft_pass_setup(const float *plane, int H, int W, 
         fs[j] = d == 0 ? f[0] : d == 1 ? f[1] : d == 2 ? f[2] : f[3];
         ss[j] = d == 0 ? stride[0] : d == 1 ? stride[1] : d == 2 ? stride[2] : stride[3];
         p.src[j] = d == 0 ? pix[0] : d == 1 ? pix[1] : d == 2 ? pix[2] : pix[3];
+    }
+    {
+        const int tstride[4] = {kTubeSA, kTubeSB, kTubeSC, kTubeSD};
+        int ts[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = o[j];
+            ts[j] = d == 0 ? tstride[0] : d == 1 ? tstride[1] : d == 2 ? tstride[2] : tstride[3];
+        }
+        p.tslot[0] = tube_slot(h[0], h[1], h[2], h[3]);
+        p.tslot[1] = p.tslot[0] + ts[0];
+        p.tslot[2] = p.tslot[1] + ts[1];
+        p.tslot[3] = p.tslot[2] + ts[2];
+        p.tslot[4] = p.tslot[3] + ts[3];
+        const int hx = imax(imax(h[0], h[1]), imax(h[2], h[3])), hn = imin(imin(h[0], h[1]), imin(h[2], h[3]));
+        p.in_tube = hx - hn <= 1 && hn >= 0 && hx <= 15;
     }
     p.idx[0] = h[0] * kStrideA + h[1] * kStrideB + h[2] * kStrideC + h[3];
     p.idx[1] = p.idx[0] + ss[0];
@@ -149,57 +167,214 @@ __global__ void __launch_bounds__(256) ft_stage_fwd(FtArgs a) {
     });
 }
 
+// Backward of one stage.  A workgroup owns 256 consecutive sites.  Per site (one thread): recompute the stage forward for
+// the clamp mask, g = dL/d pred; then per pass the five rows' dot products with g give the input gradient (one atomic
+// per rank into the source pixel: adjacent sites hit adjacent floats, i.e. well-shaped 256-byte atomic instructions).
+// The TABLE gradient is not scattered from the site threads (64 lanes -> 64 different rows = 64 memory-side atomic
+// requests per instruction): every pass writes its (row, weight / q) items to LDS and the workgroup redistributes them
+//   u > 1 : EPL lanes per item, one per row element: a wave instruction adds whole 16-float rows (64-byte segments);
+//   u == 1: one float per item: items inside the tube (991 rows, the ones smooth content uses) are summed into a
+//           per-workgroup LDS copy of the tube band with ds_add_f32 and flushed once per workgroup as contiguous
+//           atomics; items outside it go to global memory directly.
+template <int U>
+__device__ __forceinline__ int eo_of_elem(int r, int e) {      // block position whose table element is e under rotation r (inverse of row_elem)
+    return r == 0 ? e : r == 1 ? U * (e % U) + (U - 1 - e / U) : r == 2 ? U * U - 1 - e : U * (U - 1 - e % U) + e / U;
+}
+
 template <int U>
 __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
+    constexpr int EL = U * U, EPL = EL <= 1 ? 1 : EL <= 4 ? 4 : 16, NT = 256;
+    __shared__ float s_g[NT][EL + 1];
+    __shared__ int s_idx[5][NT];
+    __shared__ float s_wq[5][NT];
+    __shared__ float s_band[U == 1 ? kMaxFtModes * kTubeSlots : 1];
     const long long nsite = (long long)a.B * a.C * a.H * a.W;
-    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nsite) return;
-    const int x = (int)(s % a.W), y = (int)((s / a.W) % a.H);
-    const long long bc = s / ((long long)a.W * a.H);
+    const long long s = (long long)blockIdx.x * NT + threadIdx.x;
+    const bool valid = s < nsite;
+    const long long sc = valid ? s : nsite - 1;                 // surplus threads shadow the last site and contribute nothing
+    const int x = (int)(sc % a.W), y = (int)((sc / a.W) % a.H);
+    const long long bc = sc / ((long long)a.W * a.H);
     const float *plane = a.x + bc * a.H * a.W;
     float *gplane = a.gx + bc * a.H * a.W;
-    float g[U * U];
+    if constexpr (U == 1)
+        for (int i = threadIdx.x; i < a.M * kTubeSlots; i += NT) s_band[i] = 0.0f;
+    float g[EL];
     {
-        float pred[U * U];
+        float pred[EL];
         ft_site_forward<U>(a, plane, y, x, pred);
         const float avg = a.is_last ? (float)a.M : (float)(4 * a.M), bias = a.is_last ? 0.0f : 127.0f;
         const float *pg = a.gout + bc * (long long)(a.H * U) * (a.W * U);
-        static_for<0, U * U>([&](auto E) {
+        static_for<0, EL>([&](auto E) {
             constexpr int eo = E;
             const float t = pred[eo] / avg + bias;
             const float go = pg[(long long)(y * U + eo / U) * (a.W * U) + (x * U + eo % U)];
-            g[eo] = (t >= 0.0f && t <= 255.0f) ? go / avg : 0.0f;   // clamp backward, then d(pred/avg)
+            g[eo] = (valid && t >= 0.0f && t <= 255.0f) ? go / avg : 0.0f;   // clamp backward, then d(pred/avg)
+            s_g[threadIdx.x][eo] = g[eo];
         });
     }
     for (int m = 0; m < a.M; ++m) {
         const float *tab = a.w[m];
         float *gtab = a.gw[m];
         const int di[3] = {a.di[m][0], a.di[m][1], a.di[m][2]}, dj[3] = {a.dj[m][0], a.dj[m][1], a.dj[m][2]};
-        static_for<0, 4>([&](auto R) {
-            constexpr int r = R;
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
             FtPass p;
             ft_pass_setup(plane, a.H, a.W, y, x, r, di, dj, p);
             float dsum[5];   // sum_e g * p_j[e]
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                const float *row = tab + (long long)p.idx[j] * (U * U);
-                float *grow = gtab + (long long)p.idx[j] * (U * U);
-                const float wq = p.wt[j] / (float)kQ;
+                const float *row = tab + (long long)p.idx[j] * EL;
                 float acc = 0.0f;
-                static_for<0, U * U>([&](auto E) {
-                    constexpr int eo = E;
-                    constexpr int e = row_elem(r, eo / U, eo % U, U);
+#pragma unroll
+                for (int eo = 0; eo < EL; ++eo) {
+                    const int e = r == 0 ? eo : r == 1 ? (U - 1 - eo % U) * U + eo / U : r == 2 ? EL - 1 - eo : (eo % U) * U + (U - 1 - eo / U);   // row_elem
                     acc += g[eo] * row[e];
-                    if (wq != 0.0f && g[eo] != 0.0f) atomicAdd(&grow[e], wq * g[eo]);
-                });
+                }
                 dsum[j] = acc;
+                const float wq = p.wt[j] / (float)kQ;
+                if constexpr (U == 1) {
+                    // one float per item: LDS tube band when the pass is inside the tube, else global memory
+                    const float v = wq * g[0];
+                    if (v != 0.0f) {
+                        if (p.in_tube) atomicAdd(&s_band[m * kTubeSlots + p.tslot[j]], v);
+                        else atomicAdd(&gtab[p.idx[j]], v);
+                    }
+                } else {
+                    s_idx[j][threadIdx.x] = valid ? p.idx[j] : -1;
+                    s_wq[j][threadIdx.x] = wq;
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {   // d/d f of rank j+1 = (p_{j+1} - p_j) . g / q
                 const float df = (dsum[j + 1] - dsum[j]) / (float)kQ;
                 if (df != 0.0f) atomicAdd(&gplane[p.src[j]], df);
             }
+            if constexpr (U > 1) {
+                __syncthreads();
+                const int e = (int)threadIdx.x % EPL;
+                const int eo = eo_of_elem<U>(r, e < EL ? e : 0);
+                for (int it = (int)threadIdx.x / EPL; it < 5 * NT; it += NT / EPL) {
+                    const int j = it / NT, si = it % NT;
+                    const int idx = s_idx[j][si];
+                    if (e < EL && idx >= 0) {
+                        const float v = s_wq[j][si] * s_g[si][eo];
+                        if (v != 0.0f) atomicAdd(&gtab[(long long)idx * EL + e], v);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if constexpr (U == 1) {
+        __syncthreads();
+        // flush the workgroup's tube-band sums: contiguous floats, a wave adds 256 bytes at a time
+        for (int m = 0; m < a.M; ++m) {
+            float *gtab = a.gw[m];
+            for (int A = 0; A < kL; ++A)      // tube rows of anchor MSB A: all (B, C, D) within two steps whose spread is <= 2
+                for (int i = threadIdx.x; i < 125; i += NT) {
+                    const int B = A - 2 + i / 25, C = A - 2 + (i / 5) % 5, D = A - 2 + i % 5;
+                    if (B < 0 || C < 0 || D < 0 || B >= kL || C >= kL || D >= kL || !tube_contains(A, B, C, D)) continue;
+                    const float v = s_band[m * kTubeSlots + tube_slot(A, B, C, D)];
+                    if (v != 0.0f) atomicAdd(&gtab[A * kStrideA + B * kStrideB + C * kStrideC + D], v);
+                }
+        }
+    }
+}
+
+// Backward of a stage with 16-float rows (u == 4), 1024 sites per workgroup.  Photograph-like batches send thousands of
+// sites to the same few hundred table rows; memory-side float atomics serialise per address, so the table gradient of
+// the rows inside the tube (mulut_core.h: the rows smooth content uses) is first summed in an LDS copy of the tube band
+// (1041 x 16 floats, one mode at a time, ds_add_f32) and flushed once per workgroup and mode as contiguous atomics; only
+// passes outside the tube add to global memory directly (16 lanes per row: 64-byte segments).
+// LDS: [ band gradient 1041 x 16 f32 ][ g of the 1024 sites, 17 floats each ][ per-row items: table row, tube slot, weight / q ]
+constexpr int kFtB4Sites = 1024;
+constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Sites * 12;
+__global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
+    constexpr int U = 4, EL = 16, NT = kFtB4Sites;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ft_smem[];
+    float *s_band = (float *)ft_smem;
+    float (*s_g)[17] = (float (*)[17])(ft_smem + kTubeSlots * 16 * 4);
+    int *s_idx = (int *)(ft_smem + kTubeSlots * 16 * 4 + NT * 17 * 4);
+    int *s_slot = s_idx + NT;
+    float *s_wq = (float *)(s_slot + NT);
+    const long long nsite = (long long)a.B * a.C * a.H * a.W;
+    const long long s = (long long)blockIdx.x * NT + threadIdx.x;
+    const bool valid = s < nsite;
+    const long long sc = valid ? s : nsite - 1;
+    const int x = (int)(sc % a.W), y = (int)((sc / a.W) % a.H);
+    const long long bc = sc / ((long long)a.W * a.H);
+    const float *plane = a.x + bc * a.H * a.W;
+    float *gplane = a.gx + bc * a.H * a.W;
+    float g[EL];
+    {
+        float pred[EL];
+        ft_site_forward<U>(a, plane, y, x, pred);
+        const float avg = a.is_last ? (float)a.M : (float)(4 * a.M), bias = a.is_last ? 0.0f : 127.0f;
+        const float *pg = a.gout + bc * (long long)(a.H * U) * (a.W * U);
+        static_for<0, EL>([&](auto E) {
+            constexpr int eo = E;
+            const float t = pred[eo] / avg + bias;
+            const float go = pg[(long long)(y * U + eo / U) * (a.W * U) + (x * U + eo % U)];
+            g[eo] = (valid && t >= 0.0f && t <= 255.0f) ? go / avg : 0.0f;
+            s_g[threadIdx.x][eo] = g[eo];
         });
+    }
+    const int e = (int)threadIdx.x & 15;
+    for (int m = 0; m < a.M; ++m) {
+        const float *tab = a.w[m];
+        float *gtab = a.gw[m];
+        const int di[3] = {a.di[m][0], a.di[m][1], a.di[m][2]}, dj[3] = {a.dj[m][0], a.dj[m][1], a.dj[m][2]};
+        for (int i = threadIdx.x; i < kTubeSlots * 16; i += NT) s_band[i] = 0.0f;
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            FtPass p;
+            ft_pass_setup(plane, a.H, a.W, y, x, r, di, dj, p);
+            const int eo = eo_of_elem<U>(r, e);
+            float dprev = 0.0f;
+#pragma unroll 1
+            for (int j = 0; j < 5; ++j) {
+                const int ij = j == 0 ? p.idx[0] : j == 1 ? p.idx[1] : j == 2 ? p.idx[2] : j == 3 ? p.idx[3] : p.idx[4];
+                const int tj = j == 0 ? p.tslot[0] : j == 1 ? p.tslot[1] : j == 2 ? p.tslot[2] : j == 3 ? p.tslot[3] : p.tslot[4];
+                const float wj = j == 0 ? p.wt[0] : j == 1 ? p.wt[1] : j == 2 ? p.wt[2] : j == 3 ? p.wt[3] : p.wt[4];
+                const float *row = tab + (long long)ij * EL;
+                float acc = 0.0f;
+#pragma unroll
+                for (int q = 0; q < EL; ++q) {
+                    const int el = r == 0 ? q : r == 1 ? (U - 1 - q % U) * U + q / U : r == 2 ? EL - 1 - q : (q % U) * U + (U - 1 - q / U);   // row_elem
+                    acc += g[q] * row[el];
+                }
+                if (j > 0) {     // d/d f of rank j = (p_j - p_{j-1}) . g / q
+                    const int sj = j == 1 ? p.src[0] : j == 2 ? p.src[1] : j == 3 ? p.src[2] : p.src[3];
+                    const float df = (acc - dprev) / (float)kQ;
+                    if (df != 0.0f) atomicAdd(&gplane[sj], df);
+                }
+                dprev = acc;
+                __syncthreads();      // the previous row's items have been consumed (first trip: band zeroed, s_g written)
+                s_idx[threadIdx.x] = valid ? ij : -1;
+                s_slot[threadIdx.x] = p.in_tube ? tj : -1;
+                s_wq[threadIdx.x] = wj / (float)kQ;
+                __syncthreads();
+                for (int it = (int)threadIdx.x >> 4; it < NT; it += NT / 16) {
+                    const int idx = s_idx[it];
+                    if (idx < 0) continue;
+                    const float v = s_wq[it] * s_g[it][eo];
+                    if (v == 0.0f) continue;
+                    const int slot = s_slot[it];
+                    if (slot >= 0) atomicAdd(&s_band[slot * 16 + e], v);
+                    else atomicAdd(&gtab[(long long)idx * EL + e], v);
+                }
+            }
+        }
+        __syncthreads();
+        // flush this mode's band sums: tube rows of anchor MSB A, 16 lanes per row
+        for (int A = 0; A < kL; ++A)
+            for (int i = (int)threadIdx.x >> 4; i < 125; i += NT / 16) {
+                const int B = A - 2 + i / 25, C = A - 2 + (i / 5) % 5, D = A - 2 + i % 5;
+                if (B < 0 || C < 0 || D < 0 || B >= kL || C >= kL || D >= kL || !tube_contains(A, B, C, D)) continue;
+                const float v = s_band[tube_slot(A, B, C, D) * 16 + e];
+                if (v != 0.0f) atomicAdd(&gtab[(long long)(A * kStrideA + B * kStrideB + C * kStrideC + D) * EL + e], v);
+            }
+        __syncthreads();
     }
 }
 
@@ -208,7 +383,18 @@ static hipError_t launch_ft(const FtArgs &a, bool backward, hipStream_t st) {
     const long long nsite = (long long)a.B * a.C * a.H * a.W;
     const long long nb = (nsite + 255) / 256;
     if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (backward) hipLaunchKernelGGL(ft_stage_bwd<U>, dim3((unsigned)nb), dim3(256), 0, st, a);
+    if (backward && U == 4) {
+        static bool attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void *)ft_stage_bwd4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set[dev] = true;
+        }
+        const long long nb4 = (nsite + kFtB4Sites - 1) / kFtB4Sites;
+        hipLaunchKernelGGL(ft_stage_bwd4, dim3((unsigned)nb4), dim3(kFtB4Sites), (size_t)kFtB4Lds, st, a);
+    } else if (backward) hipLaunchKernelGGL(ft_stage_bwd<U>, dim3((unsigned)nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(ft_stage_fwd<U>, dim3((unsigned)nb), dim3(256), 0, st, a);
     return hipGetLastError();
 }

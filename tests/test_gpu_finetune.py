@@ -117,7 +117,8 @@ def test_finetune_driver_reduces_loss_and_writes_luts(tmp_path):
 
 @pytest.mark.parametrize("stages,modes,scale,shape,kind", [
     (1, "y", 4, (2, 3, 5, 7), "u8"), (2, "sdy", 4, (1, 1, 1, 1), "u8"), (3, "sd", 2, (2, 1, 9, 6), "float"),
-    (2, "dy", 3, (1, 2, 6, 8), "u8"), (2, "sdy", 4, (1, 1, 10, 10), "extreme"), (2, "s", 1, (1, 1, 7, 5), "float")])
+    (2, "dy", 3, (1, 2, 6, 8), "u8"), (2, "sdy", 4, (1, 1, 10, 10), "extreme"), (2, "s", 1, (1, 1, 7, 5), "float"),
+    (2, "sdy", 4, (256, 1, 48, 48), "smooth"), (2, "sdy", 4, (16, 1, 48, 48), "u8")])
 def test_more_shapes_vs_cpu_oracle(tmp_path, stages, modes, scale, shape, kind):
     """GPU module vs the pinned CPU oracle (oracle/ft_torch.py) on shapes / configurations the fixtures do not hold."""
     from mulut_amd.finetune import MuLUT
@@ -134,6 +135,11 @@ def test_more_shapes_vs_cpu_oracle(tmp_path, stages, modes, scale, shape, kind):
         x = rng.integers(0, 256, shape).astype(np.float32) / np.float32(255)
     elif kind == "extreme":
         x = rng.choice(np.array([0, 15, 16, 240, 255], np.float32), shape) / np.float32(255)
+    elif kind == "smooth":      # BASELINE config 4's batch (bs 256 x 1 x 48 x 48) of photograph-like crops: most passes stay in the tube
+        from mulut_amd.synth import natural_frames
+        big = natural_frames(1, 1080, 1920, 1, 11)[0, :, :, 0]
+        ys, xs = rng.integers(0, 1080 - shape[2], shape[0]), rng.integers(0, 1920 - shape[3], shape[0])
+        x = np.stack([big[a:a + shape[2], b:b + shape[3]] for a, b in zip(ys, xs)])[:, None].astype(np.float32) / np.float32(255)
     else:
         x = rng.random(shape, dtype=np.float32)
     tgt = rng.random((shape[0], shape[1], shape[2] * scale, shape[3] * scale), dtype=np.float32)
@@ -148,7 +154,8 @@ def test_more_shapes_vs_cpu_oracle(tmp_path, stages, modes, scale, shape, kind):
     yg = net(xg)
     torch.nn.functional.mse_loss(yg, torch.from_numpy(tgt).cuda()).backward()
     assert np.abs(yg.detach().cpu().numpy() - yc.detach().numpy()).max() <= 1e-5
-    assert np.allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=2e-4, atol=1e-7)
+    big = shape[0] * shape[2] * shape[3] > 10000      # many float atomics per table row: summation-order noise grows with the count
+    assert np.allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=2e-4, atol=1e-6 if big else 1e-7)
     for k, w in wcpu.items():
         g = getattr(net, "weight_" + k).grad.cpu().numpy()
-        assert np.allclose(g, w.grad.numpy(), rtol=2e-4, atol=1e-7), k
+        assert np.allclose(g, w.grad.numpy(), rtol=1e-3 if big else 2e-4, atol=1e-5 if big else 1e-7), k
