@@ -238,6 +238,30 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
             HIP_TRY(ctx, hipFree(t.bandx));
             t.band = t.bandx = nullptr;
         }
+    } else if (u == 2) {
+        // tube band of a u == 2 table: 8 bytes per slot, (e0 | e1 << 16), (e2 | e3 << 16) as value + 128
+        std::vector<uint32_t> tb((size_t)kTube2BandBytes / 4, 0x00800080u);
+        for (int A = 0; A < kL; ++A)
+            for (int B = imax(0, A - 2); B <= imin(kL - 1, A + 2); ++B)
+                for (int C = imax(0, A - 2); C <= imin(kL - 1, A + 2); ++C)
+                    for (int D = imax(0, A - 2); D <= imin(kL - 1, A + 2); ++D) {
+                        if (!tube_contains(A, B, C, D)) continue;
+                        const uint8_t *e = &img[((size_t)A * kStrideA + B * kStrideB + C * kStrideC + D) * 4];
+                        tb[(size_t)tube_slot(A, B, C, D) * 2] = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+                        tb[(size_t)tube_slot(A, B, C, D) * 2 + 1] = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+                    }
+        if (t.tube && t.tube_bytes != tb.size() * 4) {
+            HIP_TRY(ctx, hipFree(t.tube));
+            t.tube = nullptr;
+        }
+        if (!t.tube) HIP_TRY(ctx, hipMalloc(&t.tube, tb.size() * 4));
+        t.tube_bytes = tb.size() * 4;
+        HIP_TRY(ctx, hipMemcpy(t.tube, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
+        if (t.band) {
+            HIP_TRY(ctx, hipFree(t.band));
+            HIP_TRY(ctx, hipFree(t.bandx));
+            t.band = t.bandx = nullptr;
+        }
     } else if (u == 4) {
         // diagonal band (mulut_core.h): rows (A,B,C,D) with B-A, C-A, D-A in [-2,2], at band_slot()
         std::vector<uint8_t> band((size_t)kBandRows * 16, 128);
@@ -427,6 +451,22 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     int mode = kOutGeneric;
     if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || C == 1)) mode = kOutPlanarU4;
     else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3) mode = kOutPackedRGBU4;
+    if (u == 2 && ctx->n_modes <= 3 && ctx->final_kernel != 1 && (unsigned long long)N * C * H * W < (1ull << 32)) {
+        // u == 2 final stage on the tube band (the 1-byte-row kernel family with 4-value rows); flagged sites recomputed from the full table
+        rc = ensure_fix(ctx, (size_t)N * C * (oy1 - oy0) * W);
+        if (rc) return rc;
+        BandArgs b2;
+        for (int m = 0; m < ctx->n_modes; ++m) b2.band[m] = ctx->tab[stage - 1][pattern_id(ctx->modes[m])].tube;
+        a.fix_count = ctx->fix;
+        a.fix_list = ctx->fix + 16;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->fix, 0, sizeof(uint32_t), st));
+        int t2w, t2h;
+        stage_u1t_tile(t2w, t2h);
+        a.tiles_x = (W + t2w - 1) / t2w;
+        a.tiles_y = (oy1 - oy0 + t2h - 1) / t2h;
+        MAIN_KERNEL(ctx, stage, st, launch_stage_u2t(a, b2, ctx->num_cus, st));
+        return MULUT_OK;
+    }
     if (!band) {
         if (u == 4 && ctx->n_modes > 4) MAIN_KERNEL(ctx, stage, st, launch_stage_up_wide4(a, st));   // merged 16-bit fields hold 4 modes at most
         else MAIN_KERNEL(ctx, stage, st, launch_stage_up(a, u, mode, st));
@@ -554,7 +594,7 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
         if (rc) return rc;
         if (ctx->n_modes <= 3) {
             const bool u1 = ctx->stages > 1 || ctx->scale == 1;
-            rc = ensure_fix(ctx, (size_t)N * H * W * (u1 ? (size_t)C : 1));
+            rc = ensure_fix(ctx, (size_t)N * H * W * ((u1 || ctx->scale == 2) ? (size_t)C : 1));
             if (rc) return rc;
             if (ctx->scale == 4) {
                 rc = ensure_sflags(ctx, (size_t)N * H * W);
@@ -708,6 +748,7 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
 const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (!ctx || !ctx->configured) return "";
     if (!is_final || ctx->scale == 1) return stage_u1_name(ctx->first_kernel);
+    if (ctx->scale == 2 && ctx->n_modes <= 3 && ctx->final_kernel != 1) return "stage_u1t_kernel<2> + stage_up_fix_site_kernel<2>";
     if (ctx->scale == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1)
         return ctx->final_kernel == 2 ? stage_band_name(kOutPackedRGBU4)
                : ctx->final_kernel == 3 ? stage_bandx_name(kOutPackedRGBU4)

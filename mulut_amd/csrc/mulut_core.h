@@ -447,10 +447,13 @@ struct TubePair1 {
     uint32_t w[5];
 };
 constexpr int kTube1BandBytes = ((kTubeSlots * 4 + 15) / 16) * 16;      // 4176
+constexpr int kTube2BandBytes = ((kTubeSlots * 8 + 15) / 16) * 16;      // 8336: u == 2 rows as four 16-bit fields (8 bytes per slot)
 MULUT_HD uint32_t pixel_code1(uint32_t v) { return ((v & 15u) << 12) | (v >> 4); }
 MULUT_HD uint32_t tube1_key(uint32_t code_pk, uint32_t stride4) { return (code_pk & 0xF000F000u) | pk_dup(stride4); }
+// SHIFT = log2(bytes per slot): 2 for 1-byte rows (one dword per slot), 3 for u == 2 rows (four 16-bit fields per slot)
+template <int SHIFT = 2>
 MULUT_HD void simplex4_tube_pair1(uint32_t k0, uint32_t base_a, uint32_t pb, uint32_t pc, uint32_t pd, TubePair1 &o) {
-    uint32_t k1 = tube1_key(pb, kTubeSB * 4), k2 = tube1_key(pc, kTubeSC * 4), k3 = tube1_key(pd, kTubeSD * 4);
+    uint32_t k1 = tube1_key(pb, kTubeSB << SHIFT), k2 = tube1_key(pc, kTubeSC << SHIFT), k3 = tube1_key(pd, kTubeSD << SHIFT);
 #if !(defined(MULUT_ABLATE) && MULUT_ABLATE == 32)   /* 32 = timing-only: no sort */
     pk_cmpx_desc(k0, k1);
     pk_cmpx_desc(k2, k3);
@@ -462,7 +465,7 @@ MULUT_HD void simplex4_tube_pair1(uint32_t k0, uint32_t base_a, uint32_t pb, uin
     // 16 * slot summed over the keys (< 16 * 1041); a quarter of it is the byte offset.  One 32-bit shift: both halves
     // are multiples of 16, so no set bit crosses over.
     const uint32_t base16 = pk_mad(pb, pk_dup(16 * kTubeSB), pk_mad(pc, pk_dup(16 * kTubeSC), pk_mad(pd, pk_dup(16 * kTubeSD), base_a)));
-    o.base = base16 >> 2;
+    o.base = base16 >> (4 - SHIFT);
     o.ks[0] = k0; o.ks[1] = k1; o.ks[2] = k2;
     o.w[0] = pk_dup(kQ) - f1;
     o.w[1] = f1 - f2;

@@ -459,6 +459,18 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant) {
     return hipGetLastError();
 }
 
+// acc += x * w[WHALF] per 16-bit lane; SWAP exchanges the halves of x (reversed rotation).  One
+// v_pk_mad_u16 each, the selects are free (op_sel / op_sel_hi).
+template <int WHALF, bool SWAP>
+__device__ __forceinline__ void pk_mac(uint32_t &acc, uint32_t x, uint32_t wpk) {
+    uint32_t r;   // three-address form: the register allocator decides whether the sum stays in place
+    if constexpr (WHALF == 0 && !SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
+    if constexpr (WHALF == 1 && !SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
+    if constexpr (WHALF == 0 && SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
+    if constexpr (WHALF == 1 && SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
+    acc = r;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1-tube: stage with 1-byte rows on the tube band (mulut_core.h).  The band of a mode is one dword per slot
 // (the int8 value as int16 in both halves): 4,176 B, so the bands of all modes stay resident next to the image
@@ -504,10 +516,26 @@ __device__ __forceinline__ uint32_t add_byte(uint32_t a, uint32_t b) {
     return r;
 }
 
+// accumulators of one site: u == 1 one int32; u == 2 two rotation-pair sets of four 16-bit fields (value + 128 rows, as
+// the u == 4 kernels: a02 holds rotations 0 and 2 -- the latter added in reversed element order -- a13 rotations 1 and 3)
+template <int U> struct U1tAcc;
+template <> struct U1tAcc<1> { int v; __device__ __forceinline__ void clear() { v = 0; } };
+template <> struct U1tAcc<2> {
+    uint32_t a02[2], a13[2];
+    __device__ __forceinline__ void clear() { a02[0] = a02[1] = a13[0] = a13[1] = 0; }
+};
+__device__ __forceinline__ uint2 lds_u64(uint32_t addr) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = *(const __attribute__((address_space(3))) u32x2 *)(uintptr_t)addr;
+    return make_uint2(v.x, v.y);
+}
+template <int U> __host__ __device__ constexpr int u1t_band_bytes() { return U == 1 ? kTube1BandBytes : kTube2BandBytes; }
+
 // rotations R and R + 2 of the pixel at window column I + 2, pattern PAT
-template <int PAT, int R, int I, int NW>
-__device__ __forceinline__ void u1t_pair(const uint32_t (&win)[5][NW], uint32_t k0, uint32_t base_a, int &acc) {
-    constexpr int BAND = PAT * kTube1BandBytes;      // LDS byte address of this pattern's band
+template <int U, int PAT, int R, int I, int NW>
+__device__ __forceinline__ void u1t_pair(const uint32_t (&win)[5][NW], uint32_t k0, uint32_t base_a, U1tAcc<U> &acc) {
+    constexpr int SHIFT = U == 1 ? 2 : 3;
+    constexpr int BAND = PAT * u1t_band_bytes<U>();      // LDS byte address of this pattern's band
     constexpr int yb = rot_dy(R, kPatDi[PAT][0], kPatDj[PAT][0]), xb = rot_dx(R, kPatDi[PAT][0], kPatDj[PAT][0]);
     constexpr int yc = rot_dy(R, kPatDi[PAT][1], kPatDj[PAT][1]), xc = rot_dx(R, kPatDi[PAT][1], kPatDj[PAT][1]);
     constexpr int yd = rot_dy(R, kPatDi[PAT][2], kPatDj[PAT][2]), xd = rot_dx(R, kPatDi[PAT][2], kPatDj[PAT][2]);
@@ -519,7 +547,7 @@ __device__ __forceinline__ void u1t_pair(const uint32_t (&win)[5][NW], uint32_t 
     const uint32_t pd = win_pair<2 + yd, I + 2 + xd, 2 - yd, I + 2 - xd, NW>(win);
 #endif
     TubePair1 bp;
-    simplex4_tube_pair1(k0, base_a, pb, pc, pd, bp);
+    simplex4_tube_pair1<SHIFT>(k0, base_a, pb, pc, pd, bp);
     // byte offsets of rows 0..3 of both passes, unpacked: row j + 1 = row j + stride byte of sorted key j
     uint32_t aa[4], ab[4];
     aa[0] = bp.base & 0xFFFFu;
@@ -529,59 +557,88 @@ __device__ __forceinline__ void u1t_pair(const uint32_t (&win)[5][NW], uint32_t 
         aa[j + 1] = add_byte<0>(aa[j], bp.ks[j]);
         ab[j + 1] = add_byte<2>(ab[j], bp.ks[j]);
     }
-    uint32_t xa[5], xb2[5];
+    constexpr int kRow4 = kTubeAll << SHIFT;
+    if constexpr (U == 1) {
+        uint32_t xa[5], xb2[5];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        constexpr int kRow4 = kTubeAll * 4;
+        for (int j = 0; j < 5; ++j) {
 #if MULUT_ABLATE == 31   /* timing-only: no band reads */
-        xa[j] = aa[j & 3] + j; xb2[j] = ab[j & 3] ^ (uint32_t)j;
+            xa[j] = aa[j & 3] + j; xb2[j] = ab[j & 3] ^ (uint32_t)j;
 #else
-        // LDS addresses as plain integers (dynamic LDS starts at 0 -- checked at kernel entry): going through the
-        // `smem` symbol would cost one v_add of a link-time zero per read
-        xa[j] = lds_u32(aa[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
-        xb2[j] = lds_u32(ab[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
+            // LDS addresses as plain integers (dynamic LDS starts at 0 -- checked at kernel entry): going through the
+            // `smem` symbol would cost one v_add of a link-time zero per read
+            xa[j] = lds_u32(aa[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
+            xb2[j] = lds_u32(ab[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
 #endif
-    }
+        }
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        typedef short s16x2 __attribute__((ext_vector_type(2)));
-        const uint32_t t = (xa[j] & 0x0000FFFFu) | (xb2[j] & 0xFFFF0000u);     // value of pass A | value of pass B
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, bp.w[j]), acc, false);
+        for (int j = 0; j < 5; ++j) {
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            const uint32_t t = (xa[j] & 0x0000FFFFu) | (xb2[j] & 0xFFFF0000u);     // value of pass A | value of pass B
+            acc.v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, bp.w[j]), acc.v, false);
+        }
+    } else {
+        uint2 xa[5], xb2[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            xa[j] = lds_u64(aa[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
+            xb2[j] = lds_u64(ab[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
+        }
+        // pass A = rotation R (fields in place, weight = low half), pass B = rotation R + 2 (element e lands on 3 - e:
+        // dwords and halves swapped, weight = high half)
+        uint32_t (&ac)[2] = R == 0 ? acc.a02 : acc.a13;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            pk_mac<0, false>(ac[0], xa[j].x, bp.w[j]);
+            pk_mac<0, false>(ac[1], xa[j].y, bp.w[j]);
+            pk_mac<1, true>(ac[0], xb2[j].y, bp.w[j]);
+            pk_mac<1, true>(ac[1], xb2[j].x, bp.w[j]);
+        }
     }
 }
 
 // all four passes of one mode for the pixel at window column I + 2 (I = 0, 1: the pixel loop takes two pixels per step)
-template <int PAT, int I>
-__device__ __forceinline__ void u1t_mode(const uint8_t *smem, const uint32_t (&win)[5][3], uint32_t &k0, uint32_t base_a, int &acc) {
-    (void)smem;
-    u1t_pair<PAT, 0, I, 3>(win, k0, base_a, acc);
+template <int U, int PAT, int I>
+__device__ __forceinline__ void u1t_mode(const uint32_t (&win)[5][3], uint32_t &k0, uint32_t base_a, U1tAcc<U> &acc) {
+    u1t_pair<U, PAT, 0, I, 3>(win, k0, base_a, acc);
     // one pair at a time: the second pair's index math must not be scheduled into the first (the window registers
-    // leave room for one pair's temporaries under the 64-VGPR budget of 8 waves per SIMD); the empty asm ties the
-    // second pair's anchor key to the first pair's sum
+    // leave room for one pair's temporaries under the VGPR budget); the empty asm ties the second pair's anchor key to
+    // the first pair's sum
 #if !defined(MULUT_VARIANT_k1ilp)
-    asm volatile("" : "+v"(acc), "+v"(k0));
+    if constexpr (U == 1) asm volatile("" : "+v"(acc.v), "+v"(k0));
+    else asm volatile("" : "+v"(acc.a02[0]), "+v"(k0));
 #endif
-    u1t_pair<PAT, 1, I, 3>(win, k0, base_a, acc);
+    u1t_pair<U, PAT, 1, I, 3>(win, k0, base_a, acc);
 }
 
-// one pixel: all modes, then the byte
-template <int I>
-__device__ __forceinline__ uint32_t u1t_pixel(const StageArgs &a, const uint8_t *smem, const uint32_t (&win)[5][3]) {
-    int acc = 0;
+// one pixel: all modes, then the byte (u == 1) or the 2 x 2 block as four bytes, row-major (u == 2)
+template <int U, int I>
+__device__ __forceinline__ uint32_t u1t_pixel(const StageArgs &a, const uint32_t (&win)[5][3]) {
+    U1tAcc<U> acc;
+    acc.clear();
     // anchor terms, the same for every mode and rotation of the pixel
     const uint32_t ca_pk = win_pair<2, I + 2, 2, I + 2, 3>(win);
-    uint32_t k0 = tube1_key(ca_pk, kTubeSA * 4);
+    uint32_t k0 = tube1_key(ca_pk, kTubeSA << (U == 1 ? 2 : 3));
     const uint32_t base_a = pk_mad(ca_pk, pk_dup(16 * kTubeSA), 0u);
     for (int mv = 0; mv < a.M; ++mv) {
         const int m = __builtin_amdgcn_readfirstlane(mv);
         const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
-        if (pat == 0) u1t_mode<0, I>(smem, win, k0, base_a, acc);
-        else if (pat == 1) u1t_mode<1, I>(smem, win, k0, base_a, acc);
-        else u1t_mode<2, I>(smem, win, k0, base_a, acc);
+        if (pat == 0) u1t_mode<U, 0, I>(win, k0, base_a, acc);
+        else if (pat == 1) u1t_mode<U, 1, I>(win, k0, base_a, acc);
+        else u1t_mode<U, 2, I>(win, k0, base_a, acc);
     }
-    if (a.use_fma)       // wave-uniform: fused float epilogue proven exact; v_cvt_pk_u8_f32 rounds to nearest even and saturates
-        return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)acc, a.inv_d, a.epi_c), 0u, 0u);
-    return rhe_clip_u8(acc + a.bias_num, a.div);
+    if constexpr (U == 1) {
+        if (a.use_fma)       // wave-uniform: fused float epilogue proven exact; v_cvt_pk_u8_f32 rounds to nearest even and saturates
+            return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)acc.v, a.inv_d, a.epi_c), 0u, 0u);
+        return rhe_clip_u8(acc.v + a.bias_num, a.div);
+    } else {
+        // block value (sy, sx) = field 2 sy + sx of the (0,2) set + field (1 - sx) 2 + sy of the (1,3) set, minus the +128 bias of the rows
+        const int unbias = 128 * kQ * 4 * a.M - a.bias_num;
+        auto fld = [](const uint32_t (&v)[2], int e) { return (int)((v[e >> 1] >> (16 * (e & 1))) & 0xFFFFu); };
+        const uint32_t o00 = rhe_clip_u8(fld(acc.a02, 0) + fld(acc.a13, 2) - unbias, a.div), o01 = rhe_clip_u8(fld(acc.a02, 1) + fld(acc.a13, 0) - unbias, a.div);
+        const uint32_t o10 = rhe_clip_u8(fld(acc.a02, 2) + fld(acc.a13, 3) - unbias, a.div), o11 = rhe_clip_u8(fld(acc.a02, 3) + fld(acc.a13, 1) - unbias, a.div);
+        return o00 | (o01 << 8) | (o10 << 16) | (o11 << 24);
+    }
 }
 
 // bit i set <=> the 5 x 5 neighbourhood of the thread's pixel i spans more than one MSB step (then some pass of the
@@ -631,18 +688,20 @@ __device__ __forceinline__ uint32_t far_apart(uint32_t a, uint32_t b) {
 #else
 #define K1T_WAVES 6      // 80 VGPRs: three 512-thread workgroups per CU (8 waves per SIMD would mean 64 VGPRs and spills in the pair loop)
 #endif
+template <int U>
 __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs a, BandArgs b, uint32_t detail_per_1024) {
     constexpr int TW = K1T_TW, TH = K1T_TH, NT = K1T_NT, PW = K1T_PW, PH = K1T_PH;
+    constexpr int BB = u1t_band_bytes<U>();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *s_tile = smem + 3 * kTube1BandBytes;
-    uint32_t *s_cnt = (uint32_t *)(smem + 3 * kTube1BandBytes + kU1tTileBytes);     // [0] detailed groups, [1] groups looked at
+    uint8_t *s_tile = smem + 3 * BB;
+    uint32_t *s_cnt = (uint32_t *)(smem + 3 * BB + kU1tTileBytes);     // [0] detailed groups, [1] groups looked at
     if (lds_addr_of(smem) != 0u) return;      // the band reads assume the dynamic LDS block starts at address 0 (no static LDS here)
 
     for (int m = 0; m < a.M; ++m) {
         const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
         const uint32_t *src = (const uint32_t *)b.band[m];
-        uint32_t *dst = (uint32_t *)(smem + pat * kTube1BandBytes);
-        for (int i = threadIdx.x; i < kTube1BandBytes / 4; i += NT) dst[i] = src[i];
+        uint32_t *dst = (uint32_t *)(smem + pat * BB);
+        for (int i = threadIdx.x; i < BB / 4; i += NT) dst[i] = src[i];
     }
     const int ntiles = a.N * a.tiles_x * a.tiles_y;
     const int G = gridDim.x;
@@ -774,26 +833,48 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
             // can be scheduled into an earlier one
 #pragma clang loop unroll(disable)
             for (int it = 0; it < 2; ++it) {
+                if (U == 2 && x + 2 * it >= a.W) break;
                 uint32_t win[5][3];
                 const uint32_t *row = (const uint32_t *)(s_tile + 2 * ((c * PH + ty) * PW + tx4 + 2 * it));
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
                     win[q][0] = row[q * (PW / 2)]; win[q][1] = row[q * (PW / 2) + 1]; win[q][2] = row[q * (PW / 2) + 2];
                 }
-                uint32_t b0 = u1t_pixel<0>(a, smem, win);
+                uint32_t b0 = u1t_pixel<U, 0>(a, win);
 #if !defined(MULUT_VARIANT_k1ilp)
                 asm volatile("" : "+v"(b0), "+v"(win[2][1]));       // the second pixel starts after the first is done
 #endif
-                const uint32_t b1 = u1t_pixel<1>(a, smem, win);
-                packed |= (b0 | (b1 << 8)) << (16 * it);
-            }
-            uint8_t *dst = const_cast<uint8_t *>(view_addr(a.out, n, c, y, x));
-            if (a.out.sX == 1 && x + 3 < a.W && (((uintptr_t)dst) & 3) == 0) {
-                *(uint32_t *)dst = packed;
-            } else {
+                const uint32_t b1 = u1t_pixel<U, 1>(a, win);
+                if constexpr (U == 1) {
+                    packed |= (b0 | (b1 << 8)) << (16 * it);
+                } else {
+                    // two 2 x 2 blocks side by side: HR rows 2y and 2y + 1, columns 2 (x + 2 it) .. + 3
+                    const int xo = 2 * (x + 2 * it);
+                    const uint32_t top = (b0 & 0xFFFFu) | (b1 << 16), bot = (b0 >> 16) | (b1 & 0xFFFF0000u);
+                    uint8_t *d0 = const_cast<uint8_t *>(view_addr(a.out, n, c, 2 * y, xo));
+                    uint8_t *d1 = const_cast<uint8_t *>(view_addr(a.out, n, c, 2 * y + 1, xo));
+                    if (a.out.sX == 1 && x + 2 * it + 1 < a.W && ((((uintptr_t)d0) | ((uintptr_t)d1)) & 3) == 0) {
+                        *(uint32_t *)d0 = top;
+                        *(uint32_t *)d1 = bot;
+                    } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (x + i < a.W) dst[i * a.out.sX] = (uint8_t)(packed >> (8 * i));
+                        for (int i = 0; i < 4; ++i)
+                            if (x + 2 * it + i / 2 < a.W) {
+                                d0[i * a.out.sX] = (uint8_t)(top >> (8 * i));
+                                d1[i * a.out.sX] = (uint8_t)(bot >> (8 * i));
+                            }
+                    }
+                }
+            }
+            if constexpr (U == 1) {
+                uint8_t *dst = const_cast<uint8_t *>(view_addr(a.out, n, c, y, x));
+                if (a.out.sX == 1 && x + 3 < a.W && (((uintptr_t)dst) & 3) == 0) {
+                    *(uint32_t *)dst = packed;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (x + i < a.W) dst[i * a.out.sX] = (uint8_t)(packed >> (8 * i));
+                }
             }
             // sites that may have left the tube: onto the fix-up list, one atomic per wave and pixel slot (rare)
 #pragma unroll
@@ -853,13 +934,13 @@ __global__ void __launch_bounds__(256) stage_u1_fix_kernel(StageArgs a) {
 void stage_u1t_tile(int &tw, int &th) { tw = K1T_TW; th = K1T_TH; }
 int g_u1t_persist = 0;      // experiment knob (mulut_set_tuning "u1t_persist")
 
-hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st) {
-    if (a.C > 3 || a.M > 3 || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
+template <int U>
+static hipError_t launch_u1t_t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st) {
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)stage_u1t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)stage_u1t_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
@@ -868,8 +949,14 @@ hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned deta
     // persist_per_cu > 0: that many persistent workgroups per CU walk XCD-contiguous tile ranges; 0: one workgroup per tile
     const long long want = g_u1t_persist > 0 ? (long long)g_u1t_persist * num_cus : ntiles;     // (three 512-thread workgroups fit a CU)
     const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
-    hipLaunchKernelGGL(stage_u1t_kernel, dim3(grid), dim3(K1T_NT), (size_t)kU1tLdsBytes, st, a, b, (uint32_t)detail_per_1024);
+    const size_t lds = 3 * (size_t)u1t_band_bytes<U>() + kU1tTileBytes + 16;
+    hipLaunchKernelGGL(stage_u1t_kernel<U>, dim3(grid), dim3(K1T_NT), lds, st, a, b, (uint32_t)detail_per_1024);
     return hipGetLastError();
+}
+
+hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st) {
+    if (a.C > 3 || a.M > 3 || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
+    return launch_u1t_t<1>(a, b, detail_per_1024, num_cus, st);
 }
 
 hipError_t launch_stage_u1w_list(const StageArgs &a, int num_cus, hipStream_t st) {
@@ -1082,18 +1169,6 @@ __device__ __forceinline__ void load_row(const void *lut, int idx, uint32_t (&ro
 #pragma unroll
         for (int k = 0; k < RW; ++k) row[k] = p[k];
     }
-}
-
-// acc += x * w[WHALF] per 16-bit lane; SWAP exchanges the halves of x (reversed rotation).  One
-// v_pk_mad_u16 each, the selects are free (op_sel / op_sel_hi).
-template <int WHALF, bool SWAP>
-__device__ __forceinline__ void pk_mac(uint32_t &acc, uint32_t x, uint32_t wpk) {
-    uint32_t r;   // three-address form: the register allocator decides whether the sum stays in place
-    if constexpr (WHALF == 0 && !SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
-    if constexpr (WHALF == 1 && !SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
-    if constexpr (WHALF == 0 && SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
-    if constexpr (WHALF == 1 && SWAP) asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(x), "v"(wpk), "v"(acc));
-    acc = r;
 }
 
 // Per-rotation SWAR accumulators with compile-time names.  u == 4 merges rotation pairs (r, r+2)
@@ -2205,6 +2280,52 @@ hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hi
     if (out_mode == kOutPlanarU4) hipLaunchKernelGGL((stage_up_fix_kernel<kOutPlanarU4>), grid, block, 0, st, a);
     else if (out_mode == kOutPackedRGBU4 && a.C == 3) hipLaunchKernelGGL((stage_up_fix_kernel<kOutPackedRGBU4>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((stage_up_fix_kernel<kOutGeneric>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+// Fix-up of the u == 2 tube kernel: every listed site (id = ((n C + c) H + y) W + x) recomputed from the full table
+template <int U>
+__global__ void __launch_bounds__(256) stage_up_fix_site_kernel(StageArgs a) {
+    const uint32_t count = *a.fix_count;
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        uint32_t id = a.fix_list[i];
+        const int x = (int)(id % (uint32_t)a.W); id /= (uint32_t)a.W;
+        const int y = (int)(id % (uint32_t)a.H); id /= (uint32_t)a.H;
+        const int c = (int)(id % (uint32_t)a.C), n = (int)(id / (uint32_t)a.C);
+        auto px = [&](int dy, int dx) {
+            const int gy = imin(imax(y + dy, ylo), yhi), gx = imin(imax(x + dx, 0), a.W - 1);
+            return (int)*view_addr(a.in, n, c, gy, gx);
+        };
+        const int va = px(0, 0);
+        RotAcc<U> acc;
+        acc.clear();
+        for (int mv = 0; mv < a.M; ++mv) {
+            const int m = __builtin_amdgcn_readfirstlane(mv);
+            const void *lut = a.lut[m];
+            const int di0 = a.di[m][0], di1 = a.di[m][1], di2 = a.di[m][2];
+            const int dj0 = a.dj[m][0], dj1 = a.dj[m][1], dj2 = a.dj[m][2];
+            static_for<0, 4>([&](auto R) {
+                constexpr int r = R;
+                int dy, dx, v0, v1, v2;
+                sample_offset(r, di0, dj0, dy, dx); v0 = px(dy, dx);
+                sample_offset(r, di1, dj1, dy, dx); v1 = px(dy, dx);
+                sample_offset(r, di2, dj2, dy, dx); v2 = px(dy, dx);
+                pass_global<U, r>(lut, va, v0, v1, v2, a, acc);
+            });
+        }
+        uint32_t o[U];
+        finish_channel<U, kOutGeneric>(a, acc, n, c, y, x, o);
+    }
+}
+
+// the same kernel family on a FINAL stage with u == 2 (4-value rows, 2 x 2 output blocks): b.band[m] = 8-byte-per-slot
+// tube band; no tile routing; flagged sites go to stage_up_fix_site_kernel through a.fix_list
+hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
+    if (a.C > 3 || a.M > 3 || !a.fix_list || !a.fix_count || a.verdict_take >= 0) return hipErrorInvalidValue;
+    hipError_t e = launch_u1t_t<2>(a, b, 0u, num_cus, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(stage_up_fix_site_kernel<2>, dim3((unsigned)(4 * num_cus)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
