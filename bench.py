@@ -269,7 +269,10 @@ def main():
     # overlaps the compute of batch k + 1.
     strips = None
     if not args.skip_strips:
-        strips = config3(args, eng, world, rank, dist_on, backend, timed)
+        try:
+            strips = config3(args, eng, world, rank, dist_on, backend, timed)
+        except Exception as exc:      # the headline line must not depend on this leg
+            strips = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
 
     if rank == 0:
         sites = F * H * W * 3                                   # LR samples per launch
