@@ -808,14 +808,23 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
         __syncthreads();      // tile in place
 #pragma clang loop unroll(disable)
         for (int half = 0; half < TH * (TW / 4) / NT; ++half) {
-        const int ty = ty0 + half * (NT / (TW / 4));
-        const int y = y0 + ty, x = x0 + tx4;
-        if (y >= a.oy1 || x >= a.W) continue;          // (no barrier below this point inside the trip)
+        if (y0 + ty0 + half * (NT / (TW / 4)) >= a.oy1 || x0 + tx4 >= a.W) continue;          // (no barrier below this point inside the trip)
+        // Thread coordinates are re-derived from an opaque copy of the thread id wherever they are needed: whatever is
+        // computed from them before the pixel loop and used after it would otherwise be parked in scratch around the loop
+        // (it needs every register), and scratch of 400k threads does not stay in L2 -- it was 0.7 GB of HBM writes per launch.
+        auto coords = [&](int &ty_, int &tx_) {
+            int t = (int)threadIdx.x;
+            asm volatile("" : "+v"(t));
+            tx_ = (t % (TW / 4)) * 4;
+            ty_ = t / (TW / 4) + half * (NT / (TW / 4));
+        };
 #pragma clang loop unroll(disable)
         for (int c = 0; c < a.C; ++c) {
             uint32_t dirty;
             {   // the 5 x 8 window of the thread's four pixels, only for the neighbourhood test
                 uint32_t win8[5][4];
+                int ty, tx4;
+                coords(ty, tx4);
                 const uint2 *row = (const uint2 *)(s_tile + 2 * ((c * PH + ty) * PW + tx4));
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
@@ -827,12 +836,16 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
 #else
                 dirty = u1t_dirty(win8);
 #endif
+                asm volatile("" : "+v"(dirty));     // computed HERE: sunk below the pixel loop, its 20 window registers would be parked in scratch
             }
             uint32_t packed = 0;
             // two pixels per step of a real loop: their 5 x 6 window is re-read (dword-aligned), nothing of a later step
             // can be scheduled into an earlier one
 #pragma clang loop unroll(disable)
             for (int it = 0; it < 2; ++it) {
+                int ty, tx4;
+                coords(ty, tx4);
+                const int y = y0 + ty, x = x0 + tx4;
                 if (U == 2 && x + 2 * it >= a.W) break;
                 uint32_t win[5][3];
                 const uint32_t *row = (const uint32_t *)(s_tile + 2 * ((c * PH + ty) * PW + tx4 + 2 * it));
@@ -866,6 +879,9 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                     }
                 }
             }
+            int ty, tx4;
+            coords(ty, tx4);
+            const int y = y0 + ty, x = x0 + tx4;
             if constexpr (U == 1) {
                 uint8_t *dst = const_cast<uint8_t *>(view_addr(a.out, n, c, y, x));
                 if (a.out.sX == 1 && x + 3 < a.W && (((uintptr_t)dst) & 3) == 0) {
