@@ -18,7 +18,7 @@ EXPORTS = [
     "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage", "mulut_pipeline",
     "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing", "mulut_last_stage_ms", "mulut_last_kernel_ms",
     "mulut_set_tuning", "mulut_kernel_name", "mulut_ft_stage_forward", "mulut_ft_stage_backward",
-    "mulut_eval_ws_doubles", "mulut_eval_y",
+    "mulut_eval_ws_doubles", "mulut_eval_y", "mulut_last_detail_counters",
 ]
 
 _libs = {}
@@ -103,6 +103,8 @@ def load(path=None):
     L.mulut_set_stage_timing.argtypes = [p, i]
     L.mulut_last_stage_ms.argtypes = [p, ctypes.POINTER(ctypes.c_float), i]
     L.mulut_last_kernel_ms.argtypes = [p, ctypes.POINTER(ctypes.c_float), i]
+    L.mulut_last_detail_counters.argtypes = [p, ctypes.POINTER(ctypes.c_uint32), i, p]
+    L.mulut_last_detail_counters.restype = i
     L.mulut_set_tuning.argtypes = [p, c_char_p, i]
     L.mulut_kernel_name.argtypes = [p, i]
     L.mulut_ft_stage_forward.argtypes = [i, p, c_char_p, i, i, p, i, i, i, i, p, p]

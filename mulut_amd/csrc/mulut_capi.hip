@@ -21,6 +21,7 @@ struct DevTable {
     void *tube = nullptr;   // "tube" band (keys spanning <= 2 MSB steps): v_num 16: expanded to 16-bit fields, two planes of kTubeSlots x 16 B;
                             // v_num 1: one dword per slot (kTube1BandBytes)
     size_t tube_bytes = 0;
+    uint8_t *slab = nullptr; // v_num 16: the table as 16 anchor slab pairs (mulut_core.h), kSlabTableBytes
     int vnum = 0;
     size_t bytes = 0;
 };
@@ -48,6 +49,11 @@ struct mulut_ctx {
     size_t fix_cap = 0;            // capacity in ids
     uint8_t *sflags = nullptr;     // site_flag_kernel's byte per pixel of the final-stage input
     size_t sflags_cap = 0;
+    uint32_t *det_ctl = nullptr;   // detailed-tile path of the final stage (launch_detail_slab): counters, items, sample ids, blocks
+    uint32_t *det_items = nullptr, *det_ids = nullptr;
+    uint4 *det_blocks = nullptr;
+    size_t det_items_cap = 0, det_ids_cap = 0, det_blocks_cap = 0;
+    int detail_kernel = 0;         // tuning "detail_kernel": 0 = anchor slabs in LDS (when the launch qualifies), 1 = full-table gather kernel
     int site_flags_on = 0;         // tuning "tube_site_flags": 1 = flags from site_flag_kernel (no per-pass test in the tube kernel: 4 % fewer
                                    // cycles there, but the conservative 5x5 flags grow the fix-up list and the hybrid gains nothing), 0 = per-pass tests
     int first_kernel = 0;   // 1-byte-row stages: 0 auto (tube kernel, detailed tiles to the window kernel), 1 the original
@@ -127,6 +133,7 @@ int mulut_destroy(mulut_ctx *ctx) {
             if (t.band) (void)hipFree(t.band);
             if (t.bandx) (void)hipFree(t.bandx);
             if (t.tube) (void)hipFree(t.tube);
+            if (t.slab) (void)hipFree(t.slab);
         }
     for (auto &w : ctx->ws)
         if (w) (void)hipFree(w);
@@ -134,6 +141,10 @@ int mulut_destroy(mulut_ctx *ctx) {
     if (ctx->fix) (void)hipFree(ctx->fix);
     if (ctx->sflags) (void)hipFree(ctx->sflags);
     if (ctx->tlist) (void)hipFree(ctx->tlist);
+    if (ctx->det_ctl) (void)hipFree(ctx->det_ctl);
+    if (ctx->det_items) (void)hipFree(ctx->det_items);
+    if (ctx->det_ids) (void)hipFree(ctx->det_ids);
+    if (ctx->det_blocks) (void)hipFree(ctx->det_blocks);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &p : ctx->evk)
@@ -306,12 +317,26 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
         if (!t.tube) HIP_TRY(ctx, hipMalloc(&t.tube, tb.size() * 4));
         t.tube_bytes = tb.size() * 4;
         HIP_TRY(ctx, hipMemcpy(t.tube, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
+        // anchor slab pairs: pair A = rows (A, b, c, d) and (A + 1, b, c, d) interleaved, 32 bytes per (b, c, d)
+        std::vector<uint8_t> sl((size_t)kSlabTableBytes + 1024, 128);      // the LDS copy of a pair moves whole KiB
+        for (int A = 0; A < 16; ++A)
+            for (int bcd = 0; bcd < kStrideA; ++bcd)
+                for (int f = 0; f < 2; ++f)
+                    memcpy(&sl[(size_t)A * kSlabPairBytes + (size_t)bcd * 32 + (size_t)f * 16], &img[((size_t)(A + f) * kStrideA + bcd) * 16], 16);
+        if (!t.slab) HIP_TRY(ctx, hipMalloc((void **)&t.slab, sl.size()));
+        HIP_TRY(ctx, hipMemcpy(t.slab, sl.data(), sl.size(), hipMemcpyHostToDevice));
     } else {
         if (t.band) HIP_TRY(ctx, hipFree(t.band));
         if (t.bandx) HIP_TRY(ctx, hipFree(t.bandx));
         if (t.tube) HIP_TRY(ctx, hipFree(t.tube));
+        if (t.slab) HIP_TRY(ctx, hipFree(t.slab));
         t.band = t.bandx = t.tube = nullptr;
+        t.slab = nullptr;
         t.tube_bytes = 0;
+    }
+    if (u != 4 && t.slab) {
+        HIP_TRY(ctx, hipFree(t.slab));
+        t.slab = nullptr;
     }
     return MULUT_OK;
 }
@@ -385,6 +410,7 @@ static int ensure_verdict(mulut_ctx *ctx, size_t tiles);
 static int ensure_fix(mulut_ctx *ctx, size_t ids);
 static int ensure_tlist(mulut_ctx *ctx, size_t tiles);
 static int ensure_sflags(mulut_ctx *ctx, size_t bytes);
+static int ensure_detail(mulut_ctx *ctx, size_t items, size_t ids, size_t blocks);
 
 // Launch one stage: input view holds LR rows [in.row0, ...), outputs for LR rows [oy0, oy1).
 static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
@@ -507,6 +533,19 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.verdict_take = 0;
         if (tube) MAIN_KERNEL(ctx, stage, st, launch_stage_tube(a, b, mode, ctx->num_cus, st));
         else MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
+        if (tube && ctx->detail_kernel == 0 && detail_slab_supported(a)) {
+            // detailed tiles: samples grouped by anchor MSB, rows from the anchor's slab pair in LDS
+            rc = ensure_detail(ctx, detail_items_max(a), detail_ids_count(a), detail_blocks_count(a));
+            if (rc) return rc;
+            DetailArgs d;
+            memset(&d, 0, sizeof(d));
+            d.ctl = ctx->det_ctl; d.items = ctx->det_items; d.ids = ctx->det_ids; d.blocks = ctx->det_blocks;
+            for (int m = 0; m < 3; ++m) d.slab[m] = m < ctx->n_modes ? ctx->tab[stage - 1][pattern_id(ctx->modes[m])].slab : nullptr;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->det_ctl, 0, 64 * sizeof(uint32_t), st));
+            HIP_TRY(ctx, launch_detail_slab(a, d, mode, ctx->num_cus, st));
+            HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
+            return MULUT_OK;
+        }
         StageArgs g = a;
         int gw, gh;
         stage_up_tile(gw, gh);
@@ -573,6 +612,32 @@ static int ensure_tlist(mulut_ctx *ctx, size_t tiles) {
     return MULUT_OK;
 }
 
+static int ensure_detail(mulut_ctx *ctx, size_t items, size_t ids, size_t blocks) {
+    if (!ctx->det_ctl) HIP_TRY(ctx, hipMalloc((void **)&ctx->det_ctl, 64 * sizeof(uint32_t)));
+    if (items > ctx->det_items_cap) {
+        if (ctx->det_items) HIP_TRY(ctx, hipFree(ctx->det_items));
+        ctx->det_items = nullptr;
+        ctx->det_items_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_items, items * 2 * sizeof(uint32_t)));
+        ctx->det_items_cap = items;
+    }
+    if (ids > ctx->det_ids_cap) {
+        if (ctx->det_ids) HIP_TRY(ctx, hipFree(ctx->det_ids));
+        ctx->det_ids = nullptr;
+        ctx->det_ids_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_ids, ids * sizeof(uint32_t)));
+        ctx->det_ids_cap = ids;
+    }
+    if (blocks > ctx->det_blocks_cap) {
+        if (ctx->det_blocks) HIP_TRY(ctx, hipFree(ctx->det_blocks));
+        ctx->det_blocks = nullptr;
+        ctx->det_blocks_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_blocks, blocks * sizeof(uint4)));
+        ctx->det_blocks_cap = blocks;
+    }
+    return MULUT_OK;
+}
+
 static int ensure_verdict(mulut_ctx *ctx, size_t tiles) {
     if (tiles <= ctx->verdict_tiles) return MULUT_OK;
     if (ctx->verdict) HIP_TRY(ctx, hipFree(ctx->verdict));
@@ -599,6 +664,14 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
             if (ctx->scale == 4) {
                 rc = ensure_sflags(ctx, (size_t)N * H * W);
                 if (rc) return rc;
+                stage_band_tile(tw, th);
+                StageArgs t;
+                memset(&t, 0, sizeof(t));
+                t.N = N; t.tiles_x = (W + tw - 1) / tw; t.tiles_y = (H + th - 1) / th;
+                if ((long long)t.N * t.tiles_x * t.tiles_y < (1ll << 20)) {
+                    rc = ensure_detail(ctx, detail_items_max(t), detail_ids_count(t), detail_blocks_count(t));
+                    if (rc) return rc;
+                }
             }
             if (u1) {
                 stage_u1_tile(tw, th);
@@ -710,6 +783,22 @@ int mulut_last_kernel_ms(mulut_ctx *ctx, float *ms, int cap) {
     return n;
 }
 
+int mulut_last_detail_counters(mulut_ctx *ctx, uint32_t *out, int cap, void *stream) {
+    if (!ctx || !out || cap <= 0) return MULUT_EINVAL;
+    if (!ctx->det_ctl || !ctx->fix) return 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t ctl[64], fixn = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctl, ctx->det_ctl, sizeof(ctl), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(ctx, hipMemcpyAsync(&fixn, ctx->fix, sizeof(fixn), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    int n = 0;
+    for (int k = 0; k < 16 && n < cap; ++k) out[n++] = ctl[k];
+    if (n < cap) out[n++] = ctl[63];
+    if (n < cap) out[n++] = fixn;
+    for (int k = 48; k < 56 && n < cap; ++k) out[n++] = ctl[k];      // phase clocks of the slabclk probe build (zero otherwise)
+    return n;
+}
+
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return MULUT_EINVAL;
     if (!strcmp(key, "final_stage_kernel")) {
@@ -720,6 +809,11 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "first_stage_kernel")) {
         if (value < 0 || value > 3) return MULUT_EINVAL;
         ctx->first_kernel = value;
+        return MULUT_OK;
+    }
+    if (!strcmp(key, "detail_kernel")) {     // final-stage tiles the statistic marks detailed: 0 anchor slabs in LDS, 1 full-table gathers
+        if (value < 0 || value > 1) return MULUT_EINVAL;
+        ctx->detail_kernel = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "tube_site_flags")) {

@@ -200,6 +200,7 @@ MULUT_HD uint32_t pk_min(uint32_t a, uint32_t b) { return MULUT_UNPK(__builtin_e
 MULUT_HD uint32_t pk_max(uint32_t a, uint32_t b) { return MULUT_UNPK(__builtin_elementwise_max(MULUT_PK(a), MULUT_PK(b))); }
 MULUT_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return MULUT_UNPK(MULUT_PK(a) * MULUT_PK(b) + MULUT_PK(c)); }
 MULUT_HD uint32_t pk_shr12(uint32_t a) { return MULUT_UNPK(MULUT_PK(a) >> (unsigned short)12); }
+MULUT_HD uint32_t pk_shr4(uint32_t a) { return MULUT_UNPK(MULUT_PK(a) >> (unsigned short)4); }
 MULUT_HD uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return MULUT_UNPK(__builtin_elementwise_sub_sat(MULUT_PK(a), MULUT_PK(b))); }
 #else
 MULUT_HD uint32_t pk_add(uint32_t a, uint32_t b) { return ((a + b) & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16); }
@@ -218,6 +219,7 @@ MULUT_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
     return (((a & 0xFFFFu) * (b & 0xFFFFu) + (c & 0xFFFFu)) & 0xFFFFu) | ((((a >> 16) * (b >> 16) + (c >> 16)) & 0xFFFFu) << 16);
 }
 MULUT_HD uint32_t pk_shr12(uint32_t a) { return ((a & 0xFFFFu) >> 12) | (((a >> 16) >> 12) << 16); }
+MULUT_HD uint32_t pk_shr4(uint32_t a) { return ((a & 0xFFFFu) >> 4) | (((a >> 16) >> 4) << 16); }
 MULUT_HD uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
     const uint32_t l = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) - (b & 0xFFFFu) : 0u;
     const uint32_t h = (a >> 16) > (b >> 16) ? (a >> 16) - (b >> 16) : 0u;
@@ -473,6 +475,65 @@ MULUT_HD void simplex4_tube_pair1(uint32_t k0, uint32_t base_a, uint32_t pb, uin
     o.w[3] = f3 - f4;
     o.w[4] = f4;
 }
+
+// ---- slab pairs: the full table, two anchor slabs at a time (detailed content) ----------------------------
+// The anchor (first key) of a sample is the pixel itself in every mode and rotation, so all 12 passes of a sample use
+// rows (A, *, *, *) before the anchor's step of the path and (A + 1, *, *, *) after it.  The device image of a final
+// stage table therefore also exists as 16 "slab pairs":  pair A = rows (A, b, c, d) and (A + 1, b, c, d) interleaved,
+// 32 bytes per (b, c, d), value + 128 as uint8 -- 2 * 4913 * 16 = 157,216 bytes, which fits the LDS of one CU.  In units
+// of 16 bytes the strides are  anchor step 1, D 2, C 34, B 578: each fits the 12 bits under f in a packed sort key, and a
+// pass's row offsets are plain sums of the sorted keys' low bits, as in the tube pair math.
+//   in : k0 = anchor key pair (f << 12 | 1 per half), pb/pc/pd = neighbour BYTES of rotations r (low half) and r + 2
+//        (high half), 0x00vv00vv
+//   out: base = row 0 offset per half (16-byte units; row 4 = base + kSlabAll), step[0..2] = unit steps of path steps
+//        1..3 per half, w[5] = weights per half
+constexpr int kSlabUA = 1, kSlabUD = 2, kSlabUC = 34, kSlabUB = 578, kSlabAll = kSlabUA + kSlabUD + kSlabUC + kSlabUB;
+constexpr int kSlabPairBytes = 2 * 17 * 17 * 17 * 16;      // 157,216
+constexpr int kSlabTableBytes = 16 * kSlabPairBytes;       // one mode: 2,515,456
+struct SlabPair {
+    uint32_t base;
+    uint32_t step[3];
+    uint32_t w[5];
+};
+MULUT_HD uint32_t slab_anchor_key(uint32_t va) { return pk_dup(((va & 15u) << 12) | (uint32_t)kSlabUA); }
+MULUT_HD void simplex4_slab_pair(uint32_t k0, uint32_t pb, uint32_t pc, uint32_t pd, SlabPair &o) {
+    // byte * 4096 keeps the LSB nibble at bits 12..15 of its half (the MSB nibble leaves the half)
+    uint32_t k1 = pk_mad(pb, pk_dup(4096u), pk_dup(kSlabUB));
+    uint32_t k2 = pk_mad(pc, pk_dup(4096u), pk_dup(kSlabUC));
+    uint32_t k3 = pk_mad(pd, pk_dup(4096u), pk_dup(kSlabUD));
+    const uint32_t hb = pk_shr4(pb), hc = pk_shr4(pc), hd = pk_shr4(pd);
+    pk_cmpx_desc(k0, k1);
+    pk_cmpx_desc(k2, k3);
+    pk_cmpx_desc(k0, k2);
+    pk_cmpx_desc(k1, k3);
+    pk_cmpx_desc(k1, k2);
+    const uint32_t f1 = pk_shr12(k0), f2 = pk_shr12(k1), f3 = pk_shr12(k2), f4 = pk_shr12(k3);
+    o.base = pk_mad(hb, pk_dup(kSlabUB), pk_mad(hc, pk_dup(kSlabUC), hd + hd));     // <= 16 * 614: no carry between halves
+    o.step[0] = k0 & 0x0FFF0FFFu;
+    o.step[1] = k1 & 0x0FFF0FFFu;
+    o.step[2] = k2 & 0x0FFF0FFFu;
+    o.w[0] = pk_dup(kQ) - f1;
+    o.w[1] = f1 - f2;
+    o.w[2] = f2 - f3;
+    o.w[3] = f3 - f4;
+    o.w[4] = f4;
+}
+// Rows stay bytes (value + 128, four per dword) and are accumulated WITHOUT being split into 16-bit fields first:
+//   F += dword * w   (v_pk_mad_u16 on the raw dword: a field holds 256 * odd byte + even byte, sums wrap mod 2^16)
+//   H += (odd bytes as fields) * w
+// and at the end  even sums = F - 256 H (mod 2^16: exact, an even sum is < 2^16 for <= 4 modes),  odd sums = H:
+// three operations per dword where split + accumulate takes four.  Rotations r + 2 add the byte-reversed dword into
+// accumulator dword 3 - k (merged rotation pairs, below).
+#if defined(__HIP_DEVICE_COMPILE__)
+MULUT_HD uint32_t slab_odd_bytes(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0C030C01u); }       // (b1, b3) as fields
+MULUT_HD uint32_t slab_rev_bytes(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x00010203u); }
+MULUT_HD uint32_t slab_rev_odd_bytes(uint32_t x) { return __builtin_amdgcn_perm(0u, x, 0x0C000C02u); }   // odd bytes of the reversed dword: (b2, b0)
+#else
+MULUT_HD uint32_t slab_odd_bytes(uint32_t x) { return (x >> 8) & 0x00FF00FFu; }
+MULUT_HD uint32_t slab_rev_bytes(uint32_t x) { return (x >> 24) | ((x >> 8) & 0xFF00u) | ((x << 8) & 0xFF0000u) | (x << 24); }
+MULUT_HD uint32_t slab_rev_odd_bytes(uint32_t x) { return ((x >> 16) & 0xFFu) | ((x & 0xFFu) << 16); }
+#endif
+MULUT_HD uint32_t slab_even_sums(uint32_t F, uint32_t H) { return pk_mad(H, pk_dup(0xFF00u), F); }
 
 // ---- merged rotation pairs ----------------------------------------------------------------------------
 // Rotation r+2 maps row element e to the block position that rotation r gives element 15-e

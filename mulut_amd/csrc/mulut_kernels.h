@@ -76,6 +76,16 @@ struct BandArgs {
 
 enum K2Out { kOutGeneric = 0, kOutPlanarU4 = 1, kOutPackedRGBU4 = 2 };
 
+// device buffers of the detailed-tile path of the final stage (launch_detail_slab)
+struct DetailArgs {
+    uint32_t *ctl;             // 64 dwords: [0..15] samples per anchor MSB, [16..31] fill cursors, [32..47] list starts, [63] items
+    uint32_t *items;           // two dwords per item: anchor MSB << 28 | samples, first index into ids
+    uint32_t *ids;             // sample ids (tile << 12 | c << 10 | ty << 6 | tx) grouped by anchor MSB
+    uint4 *blocks;             // finished 4x4 blocks (four packed rows), indexed by sample id
+    const uint8_t *slab[3];    // per mode: the table as 16 slab pairs (mulut_core.h), kSlabTableBytes (+ 1 KiB of padding: the copy moves whole KiB)
+    uint32_t tx_magic, ty_magic;   // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y): set by launch_detail_slab
+};
+
 hipError_t launch_pass(const PassArgs &a, hipStream_t st);
 // non-final (or u == 1 final) stage: tables staged in LDS, one byte out per site
 // variant 0: window kernel (four adjacent pixels per thread, neighbours from registers), 1: one site per LDS read
@@ -107,6 +117,13 @@ hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode
 const char *stage_tube_name(int out_mode);
 // recompute the pixels listed in a.fix_list[0 .. *a.fix_count) from the full tables (u == 4)
 hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st);
+// detailed tiles (a.verdict[tile] == 1, 64x16 tiling) of a u == 4 final stage from anchor slabs in LDS: bucket, plan,
+// fill, slab and retile kernels; border columns are appended to a.fix_list.  d.ctl must be zero on entry.
+bool detail_slab_supported(const StageArgs &a);
+size_t detail_ids_count(const StageArgs &a);
+size_t detail_items_max(const StageArgs &a);
+size_t detail_blocks_count(const StageArgs &a);
+hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_mode, int num_cus, hipStream_t st);
 // per-tile smooth/detailed verdict for the hybrid final stage (tiles of stage_band_tile())
 hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st);
 // per-pixel tube flags (bit c: channel c's 5x5 neighbourhood spans > 1 MSB step) + the same per-tile verdict from them

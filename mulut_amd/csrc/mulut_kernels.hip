@@ -2377,4 +2377,411 @@ hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode
     return launch_tube_t<kOutGeneric>(a, b, num_cus, st);
 }
 
+// ------------------------------------------------------------------------------------------
+// Detailed tiles of the final stage (u == 4): anchor slabs in LDS instead of row gathers from L2.
+//
+// On detailed content the full-table kernel is bound by its gathers: 60 rows of 16 bytes per sample, nearly every one
+// of them a separate 128-byte line from L2 (17-145 cycles per gather instruction per CU).  The anchor of a sample (the
+// first key) is the pixel itself in all 12 passes, so the passes of a sample touch only the slab pair of its anchor MSB
+// (mulut_core.h "slab pairs": 157,216 bytes, LDS-sized).  The samples (pixel, channel) of the tiles the statistic marked
+// detailed are therefore grouped by anchor MSB, on the device and without host synchronisation:
+//   detail_bucket_kernel<false>  counts the samples of every anchor MSB (LDS histogram per tile, 16 atomics per tile)
+//   detail_plan_kernel           turns the 16 counts into list starts and work items of <= 4096 samples of one anchor
+//   detail_bucket_kernel<true>   writes the sample ids (tile << 12 | c << 10 | ty << 6 | tx) into the 16 lists
+//   stage_slab_kernel            one persistent workgroup per CU walks the items: per mode it copies the item's slab pair
+//                                into LDS (a straight 157 KB copy, L2-resident) and runs the mode's four passes of its
+//                                4 samples per thread -- rotation pairs in packed 16-bit halves as in the tube kernel,
+//                                rows by ds_read_b128, accumulated from the raw bytes (three operations per dword) -- keeping
+//                                the accumulators in registers across the modes; the finished 4x4 block of a sample is
+//                                one 16-byte store at blocks[id]
+//   detail_retile_kernel         writes the blocks of the detailed tiles to the output image in its layout
+// A sample's 5x5 window is read straight from the stage input (L2-resident), 8 unaligned bytes per row from column
+// x - 2; pixels in the first 2 / last 6 columns of the image would need edge replication inside those 8 bytes and go to
+// the pixel fix-up list (stage_up_fix_kernel) instead.
+// ------------------------------------------------------------------------------------------
+#if defined(MULUT_VARIANT_slabs3) || defined(MULUT_VARIANT_slabs3nopf)
+constexpr int kSlabNT = 1024, kSlabS = 3, kSlabItem = kSlabNT * kSlabS;
+#else
+constexpr int kSlabNT = 1024, kSlabS = 4, kSlabItem = kSlabNT * kSlabS;
+#endif
+#if defined(MULUT_VARIANT_slabs3nopf)
+#define MULUT_VARIANT_slabnopf 1
+#endif
+constexpr int kSlabXLo = 2, kSlabXHi = 6;
+constexpr int kSlabLdsBytes = ((kSlabPairBytes + 1023) / 1024) * 1024;      // whole 1-KiB LDS-DMA pieces: 157,696
+constexpr int kDetCount = 0, kDetCursor = 16, kDetStart = 32, kDetItems = 63;      // dword offsets in DetailArgs::ctl
+
+__device__ __forceinline__ uint4 lds_u128(uint32_t addr) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *(const __attribute__((address_space(3))) u32x4 *)(uintptr_t)addr;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) detail_bucket_kernel(StageArgs a, DetailArgs d) {
+    constexpr int TW = KB_TW, TH = KB_TH, PER = 3 * TW * TH / 256;
+    static_assert(TW == 64 && TH == 16, "sample ids assume the 64x16 verdict tile");
+    __shared__ uint32_t s_hist[16], s_base[16];
+    const int tile = (int)blockIdx.x;
+    if (a.verdict[tile] != 1u) return;                 // workgroup-uniform
+    int n, y0, x0;
+    decode_tile(a, tile, n, y0, x0, TW, TH);
+    if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t key[PER];                                 // anchor MSB | rank within the tile's bucket << 4
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int s = (int)threadIdx.x + k * 256;
+        const int c = s >> 10, ty = (s >> 6) & 15, tx = s & 63;
+        const int y = y0 + ty, x = x0 + tx;
+        const bool inside = c < a.C && y < a.oy1 && x < a.W;
+        const bool slab = inside && x >= kSlabXLo && x < a.W - kSlabXHi;
+        key[k] = 0xFFFFFFFFu;
+        if (slab) {
+            const uint32_t h = (uint32_t)(*view_addr(a.in, n, c, y, x) >> 4);
+            key[k] = h | (atomicAdd(&s_hist[h], 1u) << 4);
+        }
+        if (FILL && inside && !slab && c == 0) a.fix_list[atomicAdd(a.fix_count, 1u)] = (uint32_t)((n * a.H + y) * a.W + x);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const uint32_t h = s_hist[threadIdx.x];
+        if (!FILL) {
+            if (h) atomicAdd(&d.ctl[kDetCount + threadIdx.x], h);
+        } else {
+            s_base[threadIdx.x] = d.ctl[kDetStart + threadIdx.x] + (h ? atomicAdd(&d.ctl[kDetCursor + threadIdx.x], h) : 0u);
+        }
+    }
+    if (FILL) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (key[k] != 0xFFFFFFFFu) d.ids[s_base[key[k] & 15u] + (key[k] >> 4)] = ((uint32_t)tile << 12) | (uint32_t)((int)threadIdx.x + k * 256);
+    }
+}
+
+__global__ void __launch_bounds__(1024) detail_plan_kernel(DetailArgs d) {
+    uint32_t start = 0, item0 = 0;
+    for (int h = 0; h < 16; ++h) {
+        const uint32_t cnt = d.ctl[kDetCount + h], ni = (cnt + kSlabItem - 1) / kSlabItem;
+        if (threadIdx.x == 0) d.ctl[kDetStart + h] = start;
+        for (uint32_t i = threadIdx.x; i < ni; i += 1024) {
+            const uint32_t left = cnt - i * kSlabItem;
+            d.items[2 * (item0 + i)] = ((uint32_t)h << 28) | (left < (uint32_t)kSlabItem ? left : (uint32_t)kSlabItem);
+            d.items[2 * (item0 + i) + 1] = start + i * kSlabItem;
+        }
+        start += cnt;
+        item0 += ni;
+    }
+    if (threadIdx.x == 0) d.ctl[kDetItems] = item0;
+}
+
+// accumulators of one sample: raw (F) and odd-byte (H) sums of the rotation pairs (0, 2) and (1, 3)
+struct SlabAcc {
+    uint32_t F02[4], H02[4], F13[4], H13[4];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) F02[k] = H02[k] = F13[k] = H13[k] = 0;
+    }
+    template <int R, int HALF>
+    __device__ __forceinline__ void mac_row(const uint4 &row, uint32_t wpk) {
+        const uint32_t rd[4] = {row.x, row.y, row.z, row.w};
+        static_for<0, 4>([&](auto K) {
+            constexpr int k = K;
+            if constexpr (R == 0) { pk_mac<HALF, false>(F02[k], rd[k], wpk); pk_mac<HALF, false>(H02[k], slab_odd_bytes(rd[k]), wpk); }
+            if constexpr (R == 1) { pk_mac<HALF, false>(F13[k], rd[k], wpk); pk_mac<HALF, false>(H13[k], slab_odd_bytes(rd[k]), wpk); }
+            if constexpr (R == 2) { pk_mac<HALF, false>(F02[3 - k], slab_rev_bytes(rd[k]), wpk); pk_mac<HALF, false>(H02[3 - k], slab_rev_odd_bytes(rd[k]), wpk); }
+            if constexpr (R == 3) { pk_mac<HALF, false>(F13[3 - k], slab_rev_bytes(rd[k]), wpk); pk_mac<HALF, false>(H13[3 - k], slab_rev_odd_bytes(rd[k]), wpk); }
+        });
+    }
+    __device__ __forceinline__ void to_fields(RotAcc<4> &r) const {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r.lo02[k] = slab_even_sums(F02[k], H02[k]); r.hi02[k] = H02[k];
+            r.lo13[k] = slab_even_sums(F13[k], H13[k]); r.hi13[k] = H13[k];
+        }
+    }
+};
+
+// dst = (16-bit half HALF of x) * 16 + acc: one v_mad_u32_u16, the half picked by op_sel
+template <int HALF>
+__device__ __forceinline__ uint32_t mad16_half(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    if constexpr (HALF == 0) asm("v_mad_u32_u16 %0, %1, 16, %2 op_sel:[0,0,0,0]" : "=v"(r) : "v"(x), "v"(acc));
+    else asm("v_mad_u32_u16 %0, %1, 16, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+// the five rows of one pass from the slab pair at LDS address 0
+template <int R, int HALF>
+__device__ __forceinline__ void slab_rows(const SlabPair &sp, SlabAcc &acc) {
+    uint32_t ad[4];        // LDS byte addresses: 16 * (running sum of the path's unit steps)
+#if !defined(MULUT_VARIANT_slabmad16)
+    ad[0] = HALF ? (sp.base >> 16) : (sp.base & 0xFFFFu);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ad[j + 1] = add_word<HALF>(ad[j], sp.step[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ad[j] <<= 4;
+#else
+    ad[0] = mad16_half<HALF>(sp.base, 0u);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ad[j + 1] = mad16_half<HALF>(sp.step[j], ad[j]);
+#endif
+    uint4 row[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) row[j] = lds_u128(ad[j < 4 ? j : 0] + (uint32_t)(j < 4 ? 0 : kSlabAll * 16));
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc.template mac_row<R, HALF>(row[j], sp.w[j]);
+}
+
+// The part of a sample's 5x5 window a pattern touches.  Per window row: nothing, one dword from column x - 1
+// (columns -1..2), or 8 bytes from column x - 2 (columns -2..5).  Row 0 is always 8 bytes (the anchor is byte 2 of it).
+//   s: rows -1..1, columns -1..1;  d: rows -2/0/2, columns -2/0/2;  y: rows +-2 columns +-1, rows +-1 columns +-1, +-2
+template <int PAT>
+__host__ __device__ constexpr int slab_row_kind(int dy) {
+    return dy == 0 ? 2 : PAT == 0 ? ((dy == 1 || dy == -1) ? 1 : 0) : PAT == 1 ? ((dy & 1) == 0 ? 2 : 0) : ((dy == 1 || dy == -1) ? 2 : 1);
+}
+struct SlabWin {
+    uint32_t lo[5], hi[5];
+    // the byte at window offset (dy, dx) of pattern PAT's loads: register and byte index
+    template <int PAT, int DY, int DX>
+    __device__ __forceinline__ uint32_t reg() const {
+        constexpr int kind = slab_row_kind<PAT>(DY);
+        static_assert(kind != 0 && (kind == 2 || (DX >= -1 && DX <= 2)), "window byte not loaded for this pattern");
+        constexpr int idx = kind == 1 ? DX + 1 : DX + 2;
+        return idx < 4 ? lo[DY + 2] : hi[DY + 2];
+    }
+    template <int PAT, int DY, int DX>
+    static constexpr int byte_idx() { return (slab_row_kind<PAT>(DY) == 1 ? DX + 1 : DX + 2) & 3; }
+};
+
+// sample descriptor: byte offset of (n, c, y, x - 2) in the stage input (< 2^28) | min(y - ylo, 2) << 28 | min(yhi - y, 2) << 30
+template <int PAT>
+__device__ __forceinline__ void slab_load_window_t(const StageArgs &a, uint32_t desc, SlabWin &w) {
+    const int top = (int)((desc >> 28) & 3u), bot = (int)(desc >> 30);
+    const uint8_t *p0 = a.in.p + (desc & 0x0FFFFFFFu);
+    static_for<0, 5>([&](auto RW) {
+        constexpr int r = RW, dy = r - 2, kind = slab_row_kind<PAT>(dy);
+        // every register of the window is assigned on every pattern's path (rows the pattern does not touch: zero): stores
+        // to different elements in the three branches would be merged into one indexed store, i.e. the window put in scratch
+        w.lo[r] = 0;
+        w.hi[r] = 0;
+        if constexpr (kind != 0) {
+            const int dyc = dy < 0 ? -imin(-dy, top) : imin(dy, bot);       // edge replication at the true image borders
+            const uint8_t *p = p0 + dyc * a.in.sY;
+            if constexpr (kind == 1) {
+                uint32_t v;
+                __builtin_memcpy(&v, p + 1, 4);
+                w.lo[r] = v;
+            } else {
+                uint2 v;
+                __builtin_memcpy(&v, p, 8);
+                w.lo[r] = v.x;
+                w.hi[r] = v.y;
+            }
+        }
+    });
+}
+__device__ __forceinline__ void slab_load_window(const StageArgs &a, int pat, uint32_t desc, SlabWin &w) {
+    asm volatile("" : "+v"(desc));      // opaque: the row addresses are rebuilt here every time (hoisted out of the mode loop they would be parked in scratch)
+    if (pat == 0) slab_load_window_t<0>(a, desc, w);          // scalar branches
+    else if (pat == 1) slab_load_window_t<1>(a, desc, w);
+    else slab_load_window_t<2>(a, desc, w);
+}
+
+// neighbour K of pattern PAT: rotation R's byte in the low half, rotation R + 2's (the opposite offset) in the high half
+template <int PAT, int R, int K>
+__device__ __forceinline__ uint32_t slab_nb(const SlabWin &w) {
+    constexpr int dy = rot_dy(R, kPatDi[PAT][K], kPatDj[PAT][K]), dx = rot_dx(R, kPatDi[PAT][K], kPatDj[PAT][K]);
+    constexpr uint32_t sel = 0x0C000C00u | ((uint32_t)(4 + SlabWin::byte_idx<PAT, -dy, -dx>()) << 16) | (uint32_t)SlabWin::byte_idx<PAT, dy, dx>();
+    return __builtin_amdgcn_perm(w.template reg<PAT, -dy, -dx>(), w.template reg<PAT, dy, dx>(), sel);
+}
+template <int PAT, int R>
+__device__ __forceinline__ void slab_pair_index(const SlabWin &w, uint32_t k0, SlabPair &sp) {
+    simplex4_slab_pair(k0, slab_nb<PAT, R, 0>(w), slab_nb<PAT, R, 1>(w), slab_nb<PAT, R, 2>(w), sp);
+}
+
+// All four passes of one sample and mode.  Only the index math is specific to the pattern (a scalar switch per rotation
+// pair, ~45 instructions each); the row reads and the accumulation -- most of the code -- are shared by the patterns, which
+// keeps the loop over an item (4 samples x 3 modes) inside the instruction cache: with the pattern as a template
+// parameter of the whole body the item loop was 77 KB of code and ran 1.5x slower.
+__device__ __forceinline__ void slab_sample(int pat, const SlabWin &w, SlabAcc &acc) {
+    uint32_t k0 = slab_anchor_key((w.lo[2] >> 16) & 0xFFu);
+    static_for<0, 2>([&](auto RR) {
+        constexpr int R = RR;
+        SlabPair sp;
+        if (pat == 0) slab_pair_index<0, R>(w, k0, sp);
+        else if (pat == 1) slab_pair_index<1, R>(w, k0, sp);
+        else slab_pair_index<2, R>(w, k0, sp);
+        slab_rows<R, 0>(sp, acc);
+        slab_rows<R + 2, 1>(sp, acc);
+        // one pair at a time: the next pair's index math must not be scheduled into this one (VGPR budget)
+        asm volatile("" : "+v"(acc.F02[0]), "+v"(acc.F13[0]), "+v"(k0));
+    });
+}
+
+#if defined(MULUT_VARIANT_slabclk)
+#define SLAB_CLK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); clk[i] += t_ - clk_last; clk_last = t_; } while (0)
+#define SLAB_CLK_ARGS , unsigned long long (&clk)[4], unsigned long long &clk_last
+#define SLAB_CLK_PASS , clk, clk_last
+#else
+#define SLAB_CLK(i) do { } while (0)
+#define SLAB_CLK_ARGS
+#define SLAB_CLK_PASS
+#endif
+// one mode of one item: the slab pair into LDS (LDS-DMA: 154 pieces of 1 KiB, wave w takes pieces w, w + 16, ...), then the
+// mode's four passes of the thread's samples; the window of the next sample is in flight while the current one is computed,
+// the first one while the slab pair is copied
+__device__ __forceinline__ void slab_mode(const StageArgs &a, int pat, const uint8_t *pair, uint8_t *smem, const uint32_t (&desc)[kSlabS], SlabAcc (&acc)[kSlabS] SLAB_CLK_ARGS) {
+    SlabWin wa, wb;
+    slab_load_window(a, pat, desc[0], wa);
+    __syncthreads();                   // everyone is done with the previous slab pair
+    SLAB_CLK(0);                       // waiting for the slowest wave of the previous mode
+    {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+        constexpr int kPieces = kSlabLdsBytes / 1024;
+#pragma unroll
+        for (int k = 0; k < (kPieces + 15) / 16; ++k) {
+            const int piece = wave + 16 * k;
+            if (piece < kPieces)       // wave-uniform
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pair + piece * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(smem + piece * 1024), 16, 0, 0);
+        }
+    }
+    __syncthreads();
+    SLAB_CLK(1);                       // slab pair copy
+#if defined(MULUT_VARIANT_slabnopf)
+    static_for<0, kSlabS>([&](auto S) {
+        constexpr int s = S;
+        if constexpr (s > 0) slab_load_window(a, pat, desc[s], wa);
+        slab_sample(pat, wa, acc[s]);
+    });
+#else
+    static_for<0, kSlabS>([&](auto S) {
+        constexpr int s = S;
+        if constexpr (s + 1 < kSlabS) slab_load_window(a, pat, desc[s + 1], (s & 1) ? wa : wb);
+        slab_sample(pat, (s & 1) ? wb : wa, acc[s]);
+    });
+#endif
+    SLAB_CLK(2);                       // the mode's passes
+}
+
+__global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, DetailArgs d) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (lds_addr_of(smem) != 0u) return;      // the row reads assume the slab pair starts at LDS address 0 (no static LDS here)
+    const uint32_t nitems = d.ctl[kDetItems];
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+#if defined(MULUT_VARIANT_slabclk)
+    unsigned long long clk[4] = {0, 0, 0, 0}, clk_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const uint32_t hdr = d.items[2 * it], first = d.items[2 * it + 1];
+        const uint32_t h = hdr >> 28, cnt = hdr & 0x0FFFFFFFu;
+        uint32_t desc[kSlabS];
+#pragma unroll
+        for (int s = 0; s < kSlabS; ++s) {
+            const uint32_t i = (uint32_t)s * kSlabNT + threadIdx.x;
+            const uint32_t sid = d.ids[first + (i < cnt ? i : cnt - 1u)];          // surplus lanes recompute the last sample (never stored)
+            // tile -> (n, tile row, tile column) with the host's reciprocals (exact for tile < 2^20, 1 < divisor < 2^12)
+            const uint32_t tile = sid >> 12;
+            const uint32_t q = a.tiles_x == 1 ? tile : __umulhi(tile, d.tx_magic), tcol = tile - q * (uint32_t)a.tiles_x;
+            const uint32_t n = a.tiles_y == 1 ? q : __umulhi(q, d.ty_magic), trow = q - n * (uint32_t)a.tiles_y;
+            const int y = a.oy0 + (int)trow * KB_TH + (int)((sid >> 6) & 15u), x = (int)tcol * KB_TW + (int)(sid & 63u);
+            const uint32_t off = (uint32_t)(view_addr(a.in, (int)n, (int)((sid >> 10) & 3u), y, x - 2) - a.in.p);
+            desc[s] = off | ((uint32_t)imin(y - ylo, 2) << 28) | ((uint32_t)imin(yhi - y, 2) << 30);
+        }
+        SlabAcc acc[kSlabS];
+#pragma unroll
+        for (int s = 0; s < kSlabS; ++s) acc[s].clear();
+        for (int mv = 0; mv < a.M; ++mv) {
+            const int m = __builtin_amdgcn_readfirstlane(mv);
+            const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;     // scalar
+            const uint8_t *pair = d.slab[m] + (size_t)h * kSlabPairBytes;
+            SLAB_CLK(3);                   // item set-up / epilogue / stores
+            slab_mode(a, pat, pair, smem, desc, acc SLAB_CLK_PASS);
+        }
+#pragma unroll
+        for (int s = 0; s < kSlabS; ++s) {
+            RotAcc<4> r;
+            acc[s].to_fields(r);
+            uint32_t o[4];
+            tube_finish_rows(a, r, o);
+            const uint32_t i = (uint32_t)s * kSlabNT + threadIdx.x;
+            if (i < cnt) d.blocks[d.ids[first + i]] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+#if defined(MULUT_VARIANT_slabclk)   /* probe build: shader-clock ticks / 1024 of wave 0 of every workgroup per phase, summed into ctl[48..51] */
+    SLAB_CLK(3);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 4; ++k) atomicAdd(&d.ctl[48 + k], (uint32_t)(clk[k] >> 10));
+#endif
+}
+
+template <int OUT>
+__global__ void __launch_bounds__(KB_TW *KB_TH) detail_retile_kernel(StageArgs a, DetailArgs d) {
+    const int tile = (int)blockIdx.x;
+    if (a.verdict[tile] != 1u) return;
+    int n, y0, x0;
+    decode_tile(a, tile, n, y0, x0, KB_TW, KB_TH);
+    const int tx = threadIdx.x % KB_TW, ty = threadIdx.x / KB_TW;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= a.oy1 || x >= a.W || x < kSlabXLo || x >= a.W - kSlabXHi) return;      // border columns: the fix-up kernel's
+    const uint32_t id = ((uint32_t)tile << 12) | (uint32_t)(ty << 6) | (uint32_t)tx;
+    if constexpr (OUT == kOutPackedRGBU4) {
+        const uint4 r = d.blocks[id], g = d.blocks[id | (1u << 10)], b = d.blocks[id | (2u << 10)];
+        const uint32_t oR[4] = {r.x, r.y, r.z, r.w}, oG[4] = {g.x, g.y, g.z, g.w}, oB[4] = {b.x, b.y, b.z, b.w};
+        store_rgb<4>(a, n, y, x, oR, oG, oB);
+    } else {
+        for (int c = 0; c < a.C; ++c) {
+            const uint4 v = d.blocks[id | ((uint32_t)c << 10)];
+            const uint32_t o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int sy = 0; sy < 4; ++sy) {
+                if constexpr (OUT == kOutPlanarU4) {
+                    *(uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n, c, y * 4 + sy, x * 4)) = o[sy];
+                } else {
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx)
+                        *const_cast<uint8_t *>(view_addr(a.out, n, c, y * 4 + sy, x * 4 + sx)) = (uint8_t)(o[sy] >> (8 * sx));
+                }
+            }
+        }
+    }
+}
+
+bool detail_slab_supported(const StageArgs &a) {
+    const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y;      // 64x16 verdict tiling
+    const unsigned long long bytes = (unsigned long long)a.N * (unsigned long long)(a.in.sN < 0 ? -a.in.sN : a.in.sN);
+    return a.C <= 3 && a.M <= 3 && a.in.sX == 1 && tiles > 0 && tiles < (1ll << 20) && a.tiles_x < 4096 && a.tiles_y < 4096 &&
+           bytes < (1ull << 28) && (unsigned long long)a.N * a.H * a.W < (1ull << 32);
+}
+size_t detail_ids_count(const StageArgs &a) { return (size_t)a.N * a.tiles_x * a.tiles_y * 3 * KB_TW * KB_TH; }
+size_t detail_items_max(const StageArgs &a) { return detail_ids_count(a) / kSlabItem + 16; }
+size_t detail_blocks_count(const StageArgs &a) { return (size_t)a.N * a.tiles_x * a.tiles_y * 4096; }
+
+// the detailed tiles (a.verdict[tile] == 1) of a u == 4 final stage; d.ctl must be zeroed (64 dwords) ahead of this call
+hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_mode, int num_cus, hipStream_t st) {
+    if (!detail_slab_supported(a) || !a.verdict || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)stage_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const unsigned tiles = (unsigned)((long long)a.N * a.tiles_x * a.tiles_y);
+    DetailArgs dd = d;
+    dd.tx_magic = make_div_magic((uint32_t)a.tiles_x).magic;
+    dd.ty_magic = make_div_magic((uint32_t)a.tiles_y).magic;
+    hipLaunchKernelGGL(detail_bucket_kernel<false>, dim3(tiles), dim3(256), 0, st, a, d);
+    hipLaunchKernelGGL(detail_plan_kernel, dim3(1), dim3(1024), 0, st, d);
+    hipLaunchKernelGGL(detail_bucket_kernel<true>, dim3(tiles), dim3(256), 0, st, a, d);
+    hipLaunchKernelGGL(stage_slab_kernel, dim3((unsigned)num_cus), dim3(kSlabNT), (size_t)kSlabLdsBytes, st, a, dd);
+    if (out_mode == kOutPlanarU4) hipLaunchKernelGGL(detail_retile_kernel<kOutPlanarU4>, dim3(tiles), dim3(KB_TW * KB_TH), 0, st, a, d);
+    else if (out_mode == kOutPackedRGBU4 && a.C == 3) hipLaunchKernelGGL(detail_retile_kernel<kOutPackedRGBU4>, dim3(tiles), dim3(KB_TW * KB_TH), 0, st, a, d);
+    else hipLaunchKernelGGL(detail_retile_kernel<kOutGeneric>, dim3(tiles), dim3(KB_TW * KB_TH), 0, st, a, d);
+    return hipGetLastError();
+}
+
 }  // namespace mulut

@@ -192,6 +192,18 @@ class MuLUTEngine:
             self._check(n)
         return [float(buf[k]) for k in range(n)]
 
+    def last_detail_counters(self):
+        """Work counters of the detailed-tile path of the last final-stage launch: dict with the samples per anchor MSB that
+        went through the anchor-slab kernel, the number of work items and the length of the pixel fix-up list."""
+        buf = (ctypes.c_uint32 * 32)()
+        n = self._lib.mulut_last_detail_counters(self._h, buf, 32, self._stream())
+        if n < 0:
+            self._check(n)
+        v = [int(buf[k]) for k in range(n)]
+        if n < 18:
+            return {"samples_per_anchor": [], "items": 0, "fix_pixels": 0, "probe": []}
+        return {"samples_per_anchor": v[:16], "items": v[16], "fix_pixels": v[17], "probe": v[18:]}
+
     def eval_y(self, gt_hwc, out_hwc, shave):
         """(PSNR, SSIM) on the Y channel of two device uint8 HWC RGB images, as sr/4_test_lut.py:313-315 scores a result
         (common/utils.py:42-101) -- computed on the device, only two doubles come back."""

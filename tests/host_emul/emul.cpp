@@ -167,6 +167,84 @@ extern "C" long emul_check_band_pair(int step) {
     return bad;
 }
 
+// Slab pairs (mulut_core.h): for every key combination the packed pair math must give the rows of the scalar simplex
+// as (anchor slab flag, (b, c, d) offset) with the same weight per row, and the raw-byte accumulation over a whole
+// sample (3 modes x 4 rotations, rotations r + 2 reversed into the pair's accumulator) must reproduce the field sums.
+extern "C" long emul_check_slab_pair(int step) {
+    long bad = 0;
+    for (int va = 0; va < 256; va += step)
+        for (int vb = 0; vb < 256; vb += step)
+            for (int vc = 0; vc < 256; vc += step)
+                for (int vd = 0; vd < 256; vd += 1) {
+                    const int vb2 = (vb * 7 + 3) & 255, vc2 = (vc * 5 + 11) & 255, vd2 = 255 - vd;
+                    SlabPair sp;
+                    simplex4_slab_pair(slab_anchor_key((uint32_t)va), (uint32_t)vb | ((uint32_t)vb2 << 16), (uint32_t)vc | ((uint32_t)vc2 << 16),
+                                       (uint32_t)vd | ((uint32_t)vd2 << 16), sp);
+                    for (int half = 0; half < 2; ++half) {
+                        const int b = half ? vb2 : vb, c = half ? vc2 : vc, d = half ? vd2 : vd;
+                        int idx[5], w[5];
+                        simplex4(va, b, c, d, idx, w);
+                        uint32_t cu[5];
+                        cu[0] = half ? (sp.base >> 16) : (sp.base & 0xFFFFu);
+                        for (int j = 0; j < 3; ++j) cu[j + 1] = cu[j] + (half ? (sp.step[j] >> 16) : (sp.step[j] & 0xFFFFu));
+                        cu[4] = cu[0] + (uint32_t)kSlabAll;
+                        uint32_t rows_s[5], rows_p[5];
+                        int wt_p[5];
+                        for (int j = 0; j < 5; ++j) {
+                            // scalar row -> unit offset inside the anchor's slab pair
+                            const int A = idx[j] / kStrideA, bcd = idx[j] % kStrideA;
+                            const int flag = A - (va >> 4);
+                            if (flag < 0 || flag > 1) { ++bad; continue; }
+                            rows_s[j] = (uint32_t)(2 * bcd + flag);
+                            rows_p[j] = cu[j];
+                            wt_p[j] = (int)(half ? (sp.w[j] >> 16) : (sp.w[j] & 0xFFFFu));
+                            if (cu[j] * 16u + 16u > (uint32_t)kSlabPairBytes) ++bad;
+                        }
+                        for (int j = 0; j < 5; ++j) {
+                            int ws = 0, wp = 0;
+                            for (int i = 0; i < 5; ++i) {
+                                if (rows_s[i] == rows_s[j]) ws += w[i];
+                                if (rows_p[i] == rows_s[j]) wp += wt_p[i];
+                            }
+                            if (ws != wp) ++bad;
+                        }
+                    }
+                }
+    // raw-byte accumulation against the field form (RotAcc<4>'s layout: lo = elements 4k, 4k+2; hi = 4k+1, 4k+3)
+    uint32_t rng = 12345u;
+    auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+    for (int trial = 0; trial < 2000; ++trial) {
+        uint32_t F[4] = {0, 0, 0, 0}, H[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        const bool extreme = trial < 4;
+        for (int pass = 0; pass < 16; ++pass) {      // four modes x (rotation r, rotation r + 2) x two visits: the merged field bound
+            const bool rev = (pass & 1) != 0;
+            int wl = 16;
+            for (int j = 0; j < 5; ++j) {
+                const int wj = j == 4 ? wl : (extreme ? (j == 0 ? 16 : 0) : (int)(next() % (uint32_t)(wl + 1)));
+                wl -= wj;
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t row = extreme ? 0xFFFFFFFFu : (next() << 8) ^ next();
+                    const uint32_t wpk = pk_dup((uint32_t)wj);
+                    if (!rev) {
+                        F[k] = pk_mad(row, wpk, F[k]);
+                        H[k] = pk_mad(slab_odd_bytes(row), wpk, H[k]);
+                        lo[k] += (row & 0x00FF00FFu) * (uint32_t)wj;
+                        hi[k] += ((row >> 8) & 0x00FF00FFu) * (uint32_t)wj;
+                    } else {
+                        F[3 - k] = pk_mad(slab_rev_bytes(row), wpk, F[3 - k]);
+                        H[3 - k] = pk_mad(slab_rev_odd_bytes(row), wpk, H[3 - k]);
+                        lo[3 - k] += bytes_3_1(row) * (uint32_t)wj;
+                        hi[3 - k] += bytes_2_0(row) * (uint32_t)wj;
+                    }
+                }
+            }
+        }
+        for (int k = 0; k < 4; ++k)
+            if (slab_even_sums(F[k], H[k]) != lo[k] || H[k] != hi[k]) ++bad;
+    }
+    return bad;
+}
+
 // tube band (mulut_core.h): the slot map must be injective on the 991 tube rows and stay inside
 // [0, kTubeSlots) for EVERY key combination; the packed pair math must give, for in-tube passes, the
 // tube slots of the scalar simplex rows with the same weight per row, for every bias the kernels use.

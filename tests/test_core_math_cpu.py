@@ -90,6 +90,13 @@ def test_band_pair_index_math(emul):
     assert emul.emul_check_band_pair(5) == 0
 
 
+def test_slab_pair_index_math_and_raw_byte_accumulation(emul):
+    """mulut_core.h slab pairs: rows / weights of the packed pair math == the scalar simplex for every key combination
+    (sampled), and F / H raw-byte accumulation == the 16-bit field sums up to the 4-mode bound"""
+    emul.emul_check_slab_pair.restype = ctypes.c_long
+    assert emul.emul_check_slab_pair(5) == 0
+
+
 def test_tube_pair_index_math(emul):
     """tube band of the final-stage kernel: injective slot map on its 991 rows, bank property, packed pair math"""
     emul.emul_check_tube_pair.restype = ctypes.c_long

@@ -33,7 +33,7 @@ COMPILER_VARIANTS = {
 
 
 def build_variant(name):
-    name = name.split("@")[0]
+    name = name.split("@")[0].split("+")[0]
     if name == "base":
         return _native.build()
     out_dir = os.path.join(ROOT, "build", "variants")
@@ -67,8 +67,10 @@ def main():
     engines = {}
     for n in names:
         e = MuLUTEngine(0, lib_path=libs[n]).configure(2, "sdy", 4, 4).set_lut_dict(luts)
+        for kv in n.split("+")[1:]:       # name[@...]+key=value: any mulut_set_tuning key
+            e.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
         if "@" in n:                      # name@final[:threshold][/first]
-            sel = n.split("@")[1]
+            sel = n.split("+")[0].split("@")[1]
             if "/" in sel:
                 sel, fst = sel.split("/")
                 e.set_tuning("first_stage_kernel", int(fst))
@@ -94,6 +96,8 @@ def main():
                 ms = engines[n].last_stage_ms()
                 if rnd:                     # round 0 = warm-up
                     res[(n, d)].append(ms)
+                if rnd == args.rounds and "clk" in n:     # probe builds: phase clocks of the anchor-slab kernel
+                    print(json.dumps({"variant": n, "dist": d, "detail": engines[n].last_detail_counters()}))
     for n in names:
         for d in data:
             a = np.asarray(res[(n, d)]) / args.frames * 1e3     # us per frame
