@@ -50,9 +50,10 @@ struct mulut_ctx {
     uint8_t *sflags = nullptr;     // site_flag_kernel's byte per pixel of the final-stage input
     size_t sflags_cap = 0;
     uint32_t *det_ctl = nullptr;   // detailed-tile path of the final stage (launch_detail_slab): counters, items, sample ids, blocks
-    uint32_t *det_items = nullptr, *det_ids = nullptr;
+    uint32_t *det_items = nullptr, *det_ids = nullptr, *det_desc = nullptr, *det_tpos = nullptr, *det_dlist = nullptr;
+    uint16_t *det_thist = nullptr;
     uint4 *det_blocks = nullptr;
-    size_t det_items_cap = 0, det_ids_cap = 0, det_blocks_cap = 0;
+    size_t det_items_cap = 0, det_ids_cap = 0, det_blocks_cap = 0, det_tiles_cap = 0;
     int detail_kernel = 0;         // tuning "detail_kernel": 0 = anchor slabs in LDS (when the launch qualifies), 1 = full-table gather kernel
     int site_flags_on = 0;         // tuning "tube_site_flags": 1 = flags from site_flag_kernel (no per-pass test in the tube kernel: 4 % fewer
                                    // cycles there, but the conservative 5x5 flags grow the fix-up list and the hybrid gains nothing), 0 = per-pass tests
@@ -144,6 +145,10 @@ int mulut_destroy(mulut_ctx *ctx) {
     if (ctx->det_ctl) (void)hipFree(ctx->det_ctl);
     if (ctx->det_items) (void)hipFree(ctx->det_items);
     if (ctx->det_ids) (void)hipFree(ctx->det_ids);
+    if (ctx->det_desc) (void)hipFree(ctx->det_desc);
+    if (ctx->det_thist) (void)hipFree(ctx->det_thist);
+    if (ctx->det_tpos) (void)hipFree(ctx->det_tpos);
+    if (ctx->det_dlist) (void)hipFree(ctx->det_dlist);
     if (ctx->det_blocks) (void)hipFree(ctx->det_blocks);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
@@ -410,7 +415,7 @@ static int ensure_verdict(mulut_ctx *ctx, size_t tiles);
 static int ensure_fix(mulut_ctx *ctx, size_t ids);
 static int ensure_tlist(mulut_ctx *ctx, size_t tiles);
 static int ensure_sflags(mulut_ctx *ctx, size_t bytes);
-static int ensure_detail(mulut_ctx *ctx, size_t items, size_t ids, size_t blocks);
+static int ensure_detail(mulut_ctx *ctx, size_t tiles, size_t items, size_t ids, size_t blocks);
 
 // Launch one stage: input view holds LR rows [in.row0, ...), outputs for LR rows [oy0, oy1).
 static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
@@ -521,11 +526,17 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         // per-tile choice on the device: smooth tiles -> LDS band kernel, detailed tiles -> full-table kernel
         rc = ensure_verdict(ctx, (size_t)N * a.tiles_x * a.tiles_y);
         if (rc) return rc;
+        // detailed tiles: samples grouped by anchor MSB, rows from the anchor's slab pair in LDS (else: the full-table gather kernel)
+        const bool slab = tube && !ctx->site_flags_on && ctx->detail_kernel == 0 && detail_slab_supported(a);
+        if (slab) {
+            rc = ensure_detail(ctx, (size_t)N * a.tiles_x * a.tiles_y, detail_items_max(a), detail_ids_count(a), detail_blocks_count(a));
+            if (rc) return rc;
+        }
         if (tube && ctx->site_flags_on) {
             HIP_TRY(ctx, launch_site_flags(a, ctx->verdict, ctx->sflags, (uint32_t)ctx->hybrid_oob_per_1024, st));
             a.site_flags = ctx->sflags;
         } else {
-            HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st));
+            HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st, slab ? ctx->det_thist : nullptr));
         }
         a.verdict = ctx->verdict;
         a.vt_x = a.tiles_x;
@@ -533,15 +544,12 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.verdict_take = 0;
         if (tube) MAIN_KERNEL(ctx, stage, st, launch_stage_tube(a, b, mode, ctx->num_cus, st));
         else MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
-        if (tube && ctx->detail_kernel == 0 && detail_slab_supported(a)) {
-            // detailed tiles: samples grouped by anchor MSB, rows from the anchor's slab pair in LDS
-            rc = ensure_detail(ctx, detail_items_max(a), detail_ids_count(a), detail_blocks_count(a));
-            if (rc) return rc;
+        if (slab) {
             DetailArgs d;
             memset(&d, 0, sizeof(d));
-            d.ctl = ctx->det_ctl; d.items = ctx->det_items; d.ids = ctx->det_ids; d.blocks = ctx->det_blocks;
+            d.ctl = ctx->det_ctl; d.items = ctx->det_items; d.ids = ctx->det_ids; d.desc = ctx->det_desc; d.blocks = ctx->det_blocks;
+            d.thist = ctx->det_thist; d.tpos = ctx->det_tpos; d.dlist = ctx->det_dlist;
             for (int m = 0; m < 3; ++m) d.slab[m] = m < ctx->n_modes ? ctx->tab[stage - 1][pattern_id(ctx->modes[m])].slab : nullptr;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->det_ctl, 0, 64 * sizeof(uint32_t), st));
             HIP_TRY(ctx, launch_detail_slab(a, d, mode, ctx->num_cus, st));
             HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
             return MULUT_OK;
@@ -612,8 +620,23 @@ static int ensure_tlist(mulut_ctx *ctx, size_t tiles) {
     return MULUT_OK;
 }
 
-static int ensure_detail(mulut_ctx *ctx, size_t items, size_t ids, size_t blocks) {
-    if (!ctx->det_ctl) HIP_TRY(ctx, hipMalloc((void **)&ctx->det_ctl, 64 * sizeof(uint32_t)));
+static int ensure_detail(mulut_ctx *ctx, size_t tiles, size_t items, size_t ids, size_t blocks) {
+    if (!ctx->det_ctl) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_ctl, 64 * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemset(ctx->det_ctl, 0, 64 * sizeof(uint32_t)));
+    }
+    if (tiles > ctx->det_tiles_cap) {
+        if (ctx->det_thist) HIP_TRY(ctx, hipFree(ctx->det_thist));
+        if (ctx->det_dlist) HIP_TRY(ctx, hipFree(ctx->det_dlist));
+        if (ctx->det_tpos) HIP_TRY(ctx, hipFree(ctx->det_tpos));
+        ctx->det_thist = nullptr;
+        ctx->det_dlist = ctx->det_tpos = nullptr;
+        ctx->det_tiles_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_thist, tiles * 16 * sizeof(uint16_t)));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_tpos, tiles * 16 * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_dlist, tiles * sizeof(uint32_t)));
+        ctx->det_tiles_cap = tiles;
+    }
     if (items > ctx->det_items_cap) {
         if (ctx->det_items) HIP_TRY(ctx, hipFree(ctx->det_items));
         ctx->det_items = nullptr;
@@ -623,9 +646,11 @@ static int ensure_detail(mulut_ctx *ctx, size_t items, size_t ids, size_t blocks
     }
     if (ids > ctx->det_ids_cap) {
         if (ctx->det_ids) HIP_TRY(ctx, hipFree(ctx->det_ids));
-        ctx->det_ids = nullptr;
+        if (ctx->det_desc) HIP_TRY(ctx, hipFree(ctx->det_desc));
+        ctx->det_ids = ctx->det_desc = nullptr;
         ctx->det_ids_cap = 0;
         HIP_TRY(ctx, hipMalloc((void **)&ctx->det_ids, ids * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_desc, ids * sizeof(uint32_t)));
         ctx->det_ids_cap = ids;
     }
     if (blocks > ctx->det_blocks_cap) {
@@ -669,7 +694,7 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
                 memset(&t, 0, sizeof(t));
                 t.N = N; t.tiles_x = (W + tw - 1) / tw; t.tiles_y = (H + th - 1) / th;
                 if ((long long)t.N * t.tiles_x * t.tiles_y < (1ll << 20)) {
-                    rc = ensure_detail(ctx, detail_items_max(t), detail_ids_count(t), detail_blocks_count(t));
+                    rc = ensure_detail(ctx, (size_t)t.N * t.tiles_x * t.tiles_y, detail_items_max(t), detail_ids_count(t), detail_blocks_count(t));
                     if (rc) return rc;
                 }
             }
@@ -793,7 +818,7 @@ int mulut_last_detail_counters(mulut_ctx *ctx, uint32_t *out, int cap, void *str
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     int n = 0;
     for (int k = 0; k < 16 && n < cap; ++k) out[n++] = ctl[k];
-    if (n < cap) out[n++] = ctl[63];
+    if (n < cap) out[n++] = ctl[kDetItems];
     if (n < cap) out[n++] = fixn;
     for (int k = 48; k < 56 && n < cap; ++k) out[n++] = ctl[k];      // phase clocks of the slabclk probe build (zero otherwise)
     return n;

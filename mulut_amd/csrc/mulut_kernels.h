@@ -77,13 +77,18 @@ struct BandArgs {
 enum K2Out { kOutGeneric = 0, kOutPlanarU4 = 1, kOutPackedRGBU4 = 2 };
 
 // device buffers of the detailed-tile path of the final stage (launch_detail_slab)
+constexpr int kSlabXLo = 2, kSlabXHi = 6;      // pixels with x < 2 or x >= W - 6 take the pixel fix-up list (a window row is read as 8 bytes from column x - 2)
+constexpr int kDetCount = 0, kDetStart = 16, kDetTiles = 62, kDetItems = 63;      // dword offsets in DetailArgs::ctl
 struct DetailArgs {
-    uint32_t *ctl;             // 64 dwords: [0..15] samples per anchor MSB, [16..31] fill cursors, [32..47] list starts, [63] items
+    uint32_t *ctl;             // 64 dwords: [0..15] samples per anchor MSB, [16..31] list starts, [62] detailed tiles, [63] work items
+    uint16_t *thist;           // 16 per tile: anchor-MSB histogram of a detailed tile (tile_stat_kernel)
+    uint32_t *tpos;            // 16 per tile: where the tile's samples of each anchor MSB start in ids / desc (detail_plan_kernel)
+    uint32_t *dlist;           // the detailed tiles
     uint32_t *items;           // two dwords per item: anchor MSB << 28 | samples, first index into ids
     uint32_t *ids;             // sample ids (tile << 12 | c << 10 | ty << 6 | tx) grouped by anchor MSB
+    uint32_t *desc;            // per sample: byte offset of (n, c, y, x - 2) in the stage input | row clamps (stage_slab_kernel)
     uint4 *blocks;             // finished 4x4 blocks (four packed rows), indexed by sample id
     const uint8_t *slab[3];    // per mode: the table as 16 slab pairs (mulut_core.h), kSlabTableBytes (+ 1 KiB of padding: the copy moves whole KiB)
-    uint32_t tx_magic, ty_magic;   // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y): set by launch_detail_slab
 };
 
 hipError_t launch_pass(const PassArgs &a, hipStream_t st);
@@ -118,14 +123,15 @@ const char *stage_tube_name(int out_mode);
 // recompute the pixels listed in a.fix_list[0 .. *a.fix_count) from the full tables (u == 4)
 hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st);
 // detailed tiles (a.verdict[tile] == 1, 64x16 tiling) of a u == 4 final stage from anchor slabs in LDS: bucket, plan,
-// fill, slab and retile kernels; border columns are appended to a.fix_list.  d.ctl must be zero on entry.
+// fill, slab and retile kernels; border columns are appended to a.fix_list.  d.thist comes from launch_tile_stat.
 bool detail_slab_supported(const StageArgs &a);
 size_t detail_ids_count(const StageArgs &a);
 size_t detail_items_max(const StageArgs &a);
 size_t detail_blocks_count(const StageArgs &a);
 hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_mode, int num_cus, hipStream_t st);
 // per-tile smooth/detailed verdict for the hybrid final stage (tiles of stage_band_tile())
-hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st);
+// thist (optional): [tile][16] anchor-MSB histograms of the detailed tiles for launch_detail_slab
+hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st, uint16_t *thist = nullptr);
 // per-pixel tube flags (bit c: channel c's 5x5 neighbourhood spans > 1 MSB step) + the same per-tile verdict from them
 hipError_t launch_site_flags(const StageArgs &a, uint32_t *verdict, uint8_t *flags, uint32_t max_per_1024, hipStream_t st);
 void stage_band_tile(int &tw, int &th);

@@ -1006,18 +1006,57 @@ hipError_t launch_stage_u1_fix(const StageArgs &a, int num_cus, hipStream_t st) 
 // detailed ones to the full-table kernel; both read the per-tile verdict from device memory, so the
 // choice costs no host synchronisation and the pipeline stays capturable into a hipGraph.
 // ------------------------------------------------------------------------------------------
+// anchor-MSB histogram of tile `tile` (of ntiles), bin b, as uint16 (a tile has 3072 samples): eight bins of one tile per
+// 16 bytes, tile-major inside a half.  The positions detail_plan_kernel derives (uint32) use the same scheme with four bins
+// per 16 bytes.
+__device__ __forceinline__ size_t detail_hist_index(uint32_t tile, uint32_t ntiles, int b) {
+    return ((size_t)(b >> 3) * ntiles + tile) * 8 + (size_t)(b & 7);
+}
+__device__ __forceinline__ size_t detail_pos_index(uint32_t tile, uint32_t ntiles, int b) {
+    return ((size_t)(b >> 2) * ntiles + tile) * 4 + (size_t)(b & 3);
+}
+
 template <int TW, int TH>
-__global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *verdict, uint32_t max_oob_per_1024) {
+__global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *verdict, uint32_t max_oob_per_1024, uint16_t *thist) {
     constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
     __shared__ uint8_t s_h[3 * PH * PW];
     __shared__ uint32_t s_cnt, s_valid;
+    __shared__ uint32_t s_hist[16];
     int n, y0, x0;
     const int id = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles on one XCD: halo lines fetched once
     decode_tile(a, id, n, y0, x0, TW, TH);
     if (threadIdx.x == 0) { s_cnt = 0; s_valid = 0; }
     const int total = a.C * PH * PW;
     const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
-    {   // every byte load of the thread in flight before the first LDS store (the kernel is nothing but latency)
+    // Planar input whose rows start on dword boundaries (the pipeline's intermediate images): aligned dwords covering
+    // image columns x0-4 .. x0+67, all in flight before the first LDS store (the kernel is nothing but latency); columns left
+    // of 0 / right of W-1 replicate the edge byte.  Any other input: byte loads.
+    const bool planar = a.in.sX == 1 && ((a.W | a.in.sY | a.in.sC) & 3) == 0 && (a.in.sN & 3) == 0 && (((uintptr_t)a.in.p) & 3) == 0;
+    if (planar) {
+        constexpr int GR = (TW + 8) / 4, PER4 = (3 * PH * GR + 255) / 256;
+        uint32_t v[PER4];
+#pragma unroll
+        for (int k = 0; k < PER4; ++k) {
+            const int i = (int)threadIdx.x + k * 256;
+            const int g = i % GR, row = (i / GR) % PH, c = imin(i / (GR * PH), a.C - 1);
+            const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
+            const int gx = x0 - 4 + 4 * g, cgx = imin(imax(gx, 0), a.W - 4);
+            uint32_t d = *(const uint32_t *)view_addr(a.in, n, c, gy, cgx);
+            if (gx < 0) d = (d & 0xFFu) * 0x01010101u;
+            else if (gx > a.W - 4) d = (d >> 24) * 0x01010101u;
+            v[k] = (d >> 4) & 0x0F0F0F0Fu;
+        }
+#pragma unroll
+        for (int k = 0; k < PER4; ++k) {
+            const int i = (int)threadIdx.x + k * 256;
+            if (i < a.C * PH * GR) {
+                const int g = i % GR, row = (i / GR) % PH, c = i / (GR * PH);
+                uint8_t *dst = s_h + (c * PH + row) * PW + 4 * g - 2;       // tile columns 4g-2 .. 4g+1
+                if (g > 0) { dst[0] = (uint8_t)v[k]; dst[1] = (uint8_t)(v[k] >> 8); }
+                if (4 * g + 1 < PW) { dst[2] = (uint8_t)(v[k] >> 16); dst[3] = (uint8_t)(v[k] >> 24); }
+            }
+        }
+    } else {
         constexpr int PER = (3 * PH * PW + 255) / 256;
         uint8_t v[PER];
 #pragma unroll
@@ -1063,7 +1102,21 @@ __global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *v
         atomicAdd(&s_valid, valid);
     }
     __syncthreads();
-    if (threadIdx.x == 0) verdict[id] = (s_cnt * 1024u > max_oob_per_1024 * s_valid) ? 1u : 0u;   // 1 = detailed
+    const bool detailed = s_cnt * 1024u > max_oob_per_1024 * s_valid;       // workgroup-uniform
+    if (threadIdx.x == 0) verdict[id] = detailed ? 1u : 0u;
+    // a detailed tile also leaves the anchor-MSB histogram of its samples for the anchor-slab path (launch_detail_slab)
+    if (detailed && thist) {
+        if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (int s = threadIdx.x; s < a.C * TH * TW; s += 256) {
+            const int tx = s % TW, ty = (s / TW) % TH, c = s / (TW * TH);
+            const int x = x0 + tx;
+            if (y0 + ty < a.oy1 && x < a.W && x >= kSlabXLo && x < a.W - kSlabXHi)
+                atomicAdd(&s_hist[s_h[c * (PH * PW) + (ty + kHalo) * PW + (tx + kHalo)]], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) thist[detail_hist_index((uint32_t)id, gridDim.x, (int)threadIdx.x)] = (uint16_t)s_hist[threadIdx.x];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1674,10 +1727,10 @@ __global__ void __launch_bounds__(TW *TH) stage_band_kernel(StageArgs a, BandArg
 constexpr int KB_TW = 64, KB_TH = 16;
 void stage_band_tile(int &tw, int &th) { tw = KB_TW; th = KB_TH; }
 
-hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st) {
+hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st, uint16_t *thist) {
     const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;   // a.tiles_* must be the 64x16 tiling
     if (nb <= 0 || nb > 0x7fffffffLL || a.C > 3) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((tile_stat_kernel<KB_TW, KB_TH>), dim3((unsigned)nb), dim3(256), 0, st, a, verdict, max_oob_per_1024);
+    hipLaunchKernelGGL((tile_stat_kernel<KB_TW, KB_TH>), dim3((unsigned)nb), dim3(256), 0, st, a, verdict, max_oob_per_1024, thist);
     return hipGetLastError();
 }
 const char *stage_band_name(int out_mode) {
@@ -2407,9 +2460,7 @@ constexpr int kSlabNT = 1024, kSlabS = 4, kSlabItem = kSlabNT * kSlabS;
 #if defined(MULUT_VARIANT_slabs3nopf)
 #define MULUT_VARIANT_slabnopf 1
 #endif
-constexpr int kSlabXLo = 2, kSlabXHi = 6;
 constexpr int kSlabLdsBytes = ((kSlabPairBytes + 1023) / 1024) * 1024;      // whole 1-KiB LDS-DMA pieces: 157,696
-constexpr int kDetCount = 0, kDetCursor = 16, kDetStart = 32, kDetItems = 63;      // dword offsets in DetailArgs::ctl
 
 __device__ __forceinline__ uint4 lds_u128(uint32_t addr) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -2417,63 +2468,186 @@ __device__ __forceinline__ uint4 lds_u128(uint32_t addr) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <bool FILL>
-__global__ void __launch_bounds__(256) detail_bucket_kernel(StageArgs a, DetailArgs d) {
-    constexpr int TW = KB_TW, TH = KB_TH, PER = 3 * TW * TH / 256;
-    static_assert(TW == 64 && TH == 16, "sample ids assume the 64x16 verdict tile");
-    __shared__ uint32_t s_hist[16], s_base[16];
-    const int tile = (int)blockIdx.x;
-    if (a.verdict[tile] != 1u) return;                 // workgroup-uniform
-    int n, y0, x0;
-    decode_tile(a, tile, n, y0, x0, TW, TH);
-    if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t key[PER];                                 // anchor MSB | rank within the tile's bucket << 4
+// One workgroup: the per-tile histograms of the detailed tiles (thist[tile][16], written by tile_stat_kernel) become
+// absolute positions in the id lists (exclusive scan over tiles per anchor MSB, in place), the 16 totals become list
+// starts and work items, and the detailed tiles are listed (dlist) -- no atomics, so the lists are deterministic.
+__global__ void __launch_bounds__(1024) detail_plan_kernel(DetailArgs d, const uint32_t *verdict, uint32_t ntiles, uint32_t want_items) {
+    __shared__ uint32_t s_wave[16][17];
+    __shared__ uint32_t s_start[17], s_item0[17], s_isz;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    // thread t takes tiles t, t + 1024, ...: the histogram halves (detail_hist_index) are then read as whole coalesced KiB per
+    // wave; the lists follow this order
+    const uint4 *half[2] = {(const uint4 *)d.thist, (const uint4 *)d.thist + ntiles};
+    uint32_t excl[17];       // this thread's exclusive prefix per anchor MSB (16: detailed tiles)
+    {
+        uint32_t local[17];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int s = (int)threadIdx.x + k * 256;
-        const int c = s >> 10, ty = (s >> 6) & 15, tx = s & 63;
-        const int y = y0 + ty, x = x0 + tx;
-        const bool inside = c < a.C && y < a.oy1 && x < a.W;
-        const bool slab = inside && x >= kSlabXLo && x < a.W - kSlabXHi;
-        key[k] = 0xFFFFFFFFu;
-        if (slab) {
-            const uint32_t h = (uint32_t)(*view_addr(a.in, n, c, y, x) >> 4);
-            key[k] = h | (atomicAdd(&s_hist[h], 1u) << 4);
+        for (int b = 0; b < 17; ++b) local[b] = 0;
+        // chunks of 8 tiles per thread, fully unrolled: all 24 loads of a chunk are in flight together (a rolled loop makes a
+        // round trip to L2 per iteration, and this is one workgroup)
+        for (uint32_t base = 0; base < ntiles; base += 8 * 1024) {
+            uint32_t det[8];
+            uint4 r[8][2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x, tc = t < ntiles ? t : ntiles - 1u;
+                det[k] = (t < ntiles && verdict[tc] == 1u) ? 1u : 0u;
+                r[k][0] = half[0][tc];
+                r[k][1] = half[1][tc];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t w[8] = {r[k][0].x, r[k][0].y, r[k][0].z, r[k][0].w, r[k][1].x, r[k][1].y, r[k][1].z, r[k][1].w};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) local[b] += det[k] ? ((w[b >> 1] >> (16 * (b & 1))) & 0xFFFFu) : 0u;
+                local[16] += det[k];
+            }
         }
-        if (FILL && inside && !slab && c == 0) a.fix_list[atomicAdd(a.fix_count, 1u)] = (uint32_t)((n * a.H + y) * a.W + x);
+#pragma unroll
+        for (int b = 0; b < 17; ++b) {
+            uint32_t inc = local[b];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)inc, o);
+                if (lane >= o) inc += up;
+            }
+            excl[b] = inc - local[b];
+            if (lane == 63) s_wave[wave][b] = inc;
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        const uint32_t h = s_hist[threadIdx.x];
-        if (!FILL) {
-            if (h) atomicAdd(&d.ctl[kDetCount + threadIdx.x], h);
-        } else {
-            s_base[threadIdx.x] = d.ctl[kDetStart + threadIdx.x] + (h ? atomicAdd(&d.ctl[kDetCursor + threadIdx.x], h) : 0u);
+    if (threadIdx.x < 17) {          // wave totals -> exclusive wave bases, column totals into s_start
+        uint32_t run = 0;
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t v = s_wave[w][threadIdx.x];
+            s_wave[w][threadIdx.x] = run;
+            run += v;
+        }
+        s_start[threadIdx.x] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // item size: whole items (4 samples per thread) when there is work for every workgroup, else fewer samples per thread
+        // (a multiple of the workgroup size) so that the few samples still spread over the workgroups
+        uint32_t total = 0;
+        for (int b = 0; b < 16; ++b) total += s_start[b];
+        uint32_t isz = ((total / (want_items ? want_items : 1u) + kSlabNT - 1) / kSlabNT) * kSlabNT;
+        isz = isz < (uint32_t)kSlabNT ? (uint32_t)kSlabNT : isz > (uint32_t)kSlabItem ? (uint32_t)kSlabItem : isz;
+        s_isz = isz;
+        uint32_t start = 0, item0 = 0;
+        for (int b = 0; b < 16; ++b) {
+            const uint32_t cnt = s_start[b];
+            d.ctl[kDetCount + b] = cnt;
+            d.ctl[kDetStart + b] = start;
+            s_start[b] = start;
+            s_item0[b] = item0;
+            start += cnt;
+            item0 += (cnt + isz - 1) / isz;
+        }
+        d.ctl[kDetTiles] = s_start[16];
+        d.ctl[kDetItems] = item0;
+    }
+    __syncthreads();
+    for (int b = 0; b < 16; ++b) {
+        const uint32_t isz = s_isz, cnt = d.ctl[kDetCount + b], ni = (cnt + isz - 1) / isz;
+        for (uint32_t i = threadIdx.x; i < ni; i += 1024) {
+            const uint32_t left = cnt - i * isz;
+            d.items[2 * (s_item0[b] + i)] = ((uint32_t)b << 28) | (left < isz ? left : isz);
+            d.items[2 * (s_item0[b] + i) + 1] = s_start[b] + i * isz;
         }
     }
-    if (FILL) {
-        __syncthreads();
+    {
+        uint32_t run[16], slot = s_wave[wave][16] + excl[16];
 #pragma unroll
-        for (int k = 0; k < PER; ++k)
-            if (key[k] != 0xFFFFFFFFu) d.ids[s_base[key[k] & 15u] + (key[k] >> 4)] = ((uint32_t)tile << 12) | (uint32_t)((int)threadIdx.x + k * 256);
+        for (int b = 0; b < 16; ++b) run[b] = s_start[b] + s_wave[wave][b] + excl[b];
+        uint4 *quarter[4] = {(uint4 *)d.tpos, (uint4 *)d.tpos + ntiles, (uint4 *)d.tpos + 2 * (size_t)ntiles, (uint4 *)d.tpos + 3 * (size_t)ntiles};
+        for (uint32_t base = 0; base < ntiles; base += 8 * 1024) {
+            uint32_t det[8], any = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x, tc = t < ntiles ? t : ntiles - 1u;
+                det[k] = (t < ntiles && verdict[tc] == 1u) ? 1u : 0u;
+                any |= det[k];
+            }
+            if (!__any((int)any)) continue;           // no detailed tile in this chunk of the wave: nothing to read or write
+            uint4 r[8][2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x, tc = t < ntiles ? t : ntiles - 1u;
+                r[k][0] = half[0][tc];
+                r[k][1] = half[1][tc];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (det[k]) {
+                    const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
+                    const uint32_t w[8] = {r[k][0].x, r[k][0].y, r[k][0].z, r[k][0].w, r[k][1].x, r[k][1].y, r[k][1].z, r[k][1].w};
+                    uint32_t o[16];
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) { o[b] = run[b]; run[b] += (w[b >> 1] >> (16 * (b & 1))) & 0xFFFFu; }
+                    quarter[0][t] = make_uint4(o[0], o[1], o[2], o[3]);
+                    quarter[1][t] = make_uint4(o[4], o[5], o[6], o[7]);
+                    quarter[2][t] = make_uint4(o[8], o[9], o[10], o[11]);
+                    quarter[3][t] = make_uint4(o[12], o[13], o[14], o[15]);
+                    d.dlist[slot++] = t;
+                }
+        }
     }
 }
 
-__global__ void __launch_bounds__(1024) detail_plan_kernel(DetailArgs d) {
-    uint32_t start = 0, item0 = 0;
-    for (int h = 0; h < 16; ++h) {
-        const uint32_t cnt = d.ctl[kDetCount + h], ni = (cnt + kSlabItem - 1) / kSlabItem;
-        if (threadIdx.x == 0) d.ctl[kDetStart + h] = start;
-        for (uint32_t i = threadIdx.x; i < ni; i += 1024) {
-            const uint32_t left = cnt - i * kSlabItem;
-            d.items[2 * (item0 + i)] = ((uint32_t)h << 28) | (left < (uint32_t)kSlabItem ? left : (uint32_t)kSlabItem);
-            d.items[2 * (item0 + i) + 1] = start + i * kSlabItem;
+// ids and descriptors of the samples of the listed tiles, written at the positions detail_plan_kernel assigned (the rank of
+// a sample inside its tile's share of a list comes from an LDS counter); pixels in the image's border columns go to the
+// pixel fix-up list instead
+__global__ void __launch_bounds__(256) detail_fill_kernel(StageArgs a, DetailArgs d) {
+    constexpr int TW = KB_TW, TH = KB_TH, PER = 3 * TW * TH / 256;
+    static_assert(TW == 64 && TH == 16, "sample ids assume the 64x16 verdict tile");
+    __shared__ uint32_t s_rank[16], s_base[16], s_fix[2];
+    const uint32_t ndet = d.ctl[kDetTiles];
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    for (uint32_t li = blockIdx.x; li < ndet; li += gridDim.x) {
+        const int tile = (int)d.dlist[li];
+        int n, y0, x0;
+        decode_tile(a, tile, n, y0, x0, TW, TH);
+        __syncthreads();              // the previous tile's counters are no longer read
+        if (threadIdx.x < 16) {
+            s_rank[threadIdx.x] = 0;
+            s_base[threadIdx.x] = d.tpos[detail_pos_index((uint32_t)tile, (uint32_t)(a.N * a.tiles_x * a.tiles_y), (int)threadIdx.x)];
         }
-        start += cnt;
-        item0 += ni;
+        if (threadIdx.x == 16) s_fix[0] = 0;
+        __syncthreads();
+        uint32_t pos[PER], fixr[4];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int s = (int)threadIdx.x + k * 256;
+            const int c = s >> 10, ty = (s >> 6) & 15, tx = s & 63;
+            const int y = y0 + ty, x = x0 + tx;
+            const bool inside = c < a.C && y < a.oy1 && x < a.W;
+            const bool slab = inside && x >= kSlabXLo && x < a.W - kSlabXHi;
+            pos[k] = 0xFFFFFFFFu;
+            if (slab) {
+                const uint32_t h = (uint32_t)(*view_addr(a.in, n, c, y, x) >> 4);
+                pos[k] = s_base[h] + atomicAdd(&s_rank[h], 1u);
+            }
+            if (k < 4) fixr[k] = (inside && !slab) ? atomicAdd(&s_fix[0], 1u) : 0xFFFFFFFFu;      // k < 4 <=> channel 0: each pixel once
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_fix[0]) s_fix[1] = atomicAdd(a.fix_count, s_fix[0]);      // one atomic per tile that has border pixels
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (fixr[k] != 0xFFFFFFFFu) {
+                const int s = (int)threadIdx.x + k * 256;
+                a.fix_list[s_fix[1] + fixr[k]] = (uint32_t)((n * a.H + y0 + ((s >> 6) & 15)) * a.W + x0 + (s & 63));
+            }
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (pos[k] != 0xFFFFFFFFu) {
+                const int s = (int)threadIdx.x + k * 256;
+                const int c = s >> 10, y = y0 + ((s >> 6) & 15), x = x0 + (s & 63);
+                d.ids[pos[k]] = ((uint32_t)tile << 12) | (uint32_t)s;
+                d.desc[pos[k]] = (uint32_t)(view_addr(a.in, n, c, y, x - 2) - a.in.p) | ((uint32_t)imin(y - ylo, 2) << 28) | ((uint32_t)imin(yhi - y, 2) << 30);
+            }
     }
-    if (threadIdx.x == 0) d.ctl[kDetItems] = item0;
 }
 
 // accumulators of one sample: raw (F) and odd-byte (H) sums of the rotation pairs (0, 2) and (1, 3)
@@ -2512,10 +2686,9 @@ __device__ __forceinline__ uint32_t mad16_half(uint32_t x, uint32_t acc) {
     return r;
 }
 
-// the five rows of one pass from the slab pair at LDS address 0
-template <int R, int HALF>
-__device__ __forceinline__ void slab_rows(const SlabPair &sp, SlabAcc &acc) {
-    uint32_t ad[4];        // LDS byte addresses: 16 * (running sum of the path's unit steps)
+// LDS byte addresses of rows 0..3 of the pass in half HALF: 16 * (running sum of the path's unit steps); row 4 = row 0 + kSlabAll * 16
+template <int HALF>
+__device__ __forceinline__ void slab_row_addrs(const SlabPair &sp, uint32_t (&ad)[4]) {
 #if !defined(MULUT_VARIANT_slabmad16)
     ad[0] = HALF ? (sp.base >> 16) : (sp.base & 0xFFFFu);
 #pragma unroll
@@ -2527,11 +2700,36 @@ __device__ __forceinline__ void slab_rows(const SlabPair &sp, SlabAcc &acc) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) ad[j + 1] = mad16_half<HALF>(sp.step[j], ad[j]);
 #endif
-    uint4 row[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) row[j] = lds_u128(ad[j < 4 ? j : 0] + (uint32_t)(j < 4 ? 0 : kSlabAll * 16));
-#pragma unroll
-    for (int j = 0; j < 5; ++j) acc.template mac_row<R, HALF>(row[j], sp.w[j]);
+}
+template <int J>
+__device__ __forceinline__ uint4 slab_row(const uint32_t (&ad)[4]) {
+    return lds_u128(ad[J < 4 ? J : 0] + (uint32_t)(J < 4 ? 0 : kSlabAll * 16));
+}
+
+// Both passes of a rotation pair (R in the low halves of sp, R + 2 in the high halves) from the slab pair at LDS address 0.
+// The second pass's rows are requested one by one as the first pass's rows are consumed -- into the registers those free --
+// so the LDS latency of every second pass is covered by accumulation instead of being waited for.
+template <int R>
+__device__ __forceinline__ void slab_pair_rows(const SlabPair &sp, SlabAcc &acc) {
+    uint32_t a0[4], a1[4];
+    slab_row_addrs<0>(sp, a0);
+    slab_row_addrs<1>(sp, a1);
+#if defined(MULUT_VARIANT_slabseq)
+    uint4 r0[5], r1[5];
+    static_for<0, 5>([&](auto J) { r0[J] = slab_row<J>(a0); });
+    static_for<0, 5>([&](auto J) { acc.template mac_row<R, 0>(r0[J], sp.w[J]); });
+    static_for<0, 5>([&](auto J) { r1[J] = slab_row<J>(a1); });
+    static_for<0, 5>([&](auto J) { acc.template mac_row<R + 2, 1>(r1[J], sp.w[J]); });
+#else
+    uint4 r0[5], r1[5];
+    static_for<0, 5>([&](auto J) { r0[J] = slab_row<J>(a0); });
+    static_for<0, 5>([&](auto J) {
+        acc.template mac_row<R, 0>(r0[J], sp.w[J]);
+        r1[J] = slab_row<J>(a1);
+        __builtin_amdgcn_sched_barrier(0);      // keep the order: row J of the first pass consumed, row J of the second requested
+    });
+    static_for<0, 5>([&](auto J) { acc.template mac_row<R + 2, 1>(r1[J], sp.w[J]); });
+#endif
 }
 
 // The part of a sample's 5x5 window a pattern touches.  Per window row: nothing, one dword from column x - 1
@@ -2613,8 +2811,7 @@ __device__ __forceinline__ void slab_sample(int pat, const SlabWin &w, SlabAcc &
         if (pat == 0) slab_pair_index<0, R>(w, k0, sp);
         else if (pat == 1) slab_pair_index<1, R>(w, k0, sp);
         else slab_pair_index<2, R>(w, k0, sp);
-        slab_rows<R, 0>(sp, acc);
-        slab_rows<R + 2, 1>(sp, acc);
+        slab_pair_rows<R>(sp, acc);
         // one pair at a time: the next pair's index math must not be scheduled into this one (VGPR budget)
         asm volatile("" : "+v"(acc.F02[0]), "+v"(acc.F13[0]), "+v"(k0));
     });
@@ -2632,7 +2829,7 @@ __device__ __forceinline__ void slab_sample(int pat, const SlabWin &w, SlabAcc &
 // one mode of one item: the slab pair into LDS (LDS-DMA: 154 pieces of 1 KiB, wave w takes pieces w, w + 16, ...), then the
 // mode's four passes of the thread's samples; the window of the next sample is in flight while the current one is computed,
 // the first one while the slab pair is copied
-__device__ __forceinline__ void slab_mode(const StageArgs &a, int pat, const uint8_t *pair, uint8_t *smem, const uint32_t (&desc)[kSlabS], SlabAcc (&acc)[kSlabS] SLAB_CLK_ARGS) {
+__device__ __forceinline__ void slab_mode(const StageArgs &a, int pat, uint32_t cnt, const uint8_t *pair, uint8_t *smem, const uint32_t (&desc)[kSlabS], SlabAcc (&acc)[kSlabS] SLAB_CLK_ARGS) {
     SlabWin wa, wb;
     slab_load_window(a, pat, desc[0], wa);
     __syncthreads();                   // everyone is done with the previous slab pair
@@ -2659,8 +2856,10 @@ __device__ __forceinline__ void slab_mode(const StageArgs &a, int pat, const uin
 #else
     static_for<0, kSlabS>([&](auto S) {
         constexpr int s = S;
-        if constexpr (s + 1 < kSlabS) slab_load_window(a, pat, desc[s + 1], (s & 1) ? wa : wb);
-        slab_sample(pat, (s & 1) ? wb : wa, acc[s]);
+        if ((uint32_t)s * kSlabNT < cnt) {          // workgroup-uniform: a short item leaves sample slots empty
+            if constexpr (s + 1 < kSlabS) slab_load_window(a, pat, desc[s + 1], (s & 1) ? wa : wb);
+            slab_sample(pat, (s & 1) ? wb : wa, acc[s]);
+        }
     });
 #endif
     SLAB_CLK(2);                       // the mode's passes
@@ -2670,7 +2869,6 @@ __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, Detail
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if (lds_addr_of(smem) != 0u) return;      // the row reads assume the slab pair starts at LDS address 0 (no static LDS here)
     const uint32_t nitems = d.ctl[kDetItems];
-    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
 #if defined(MULUT_VARIANT_slabclk)
     unsigned long long clk[4] = {0, 0, 0, 0}, clk_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -2681,14 +2879,7 @@ __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, Detail
 #pragma unroll
         for (int s = 0; s < kSlabS; ++s) {
             const uint32_t i = (uint32_t)s * kSlabNT + threadIdx.x;
-            const uint32_t sid = d.ids[first + (i < cnt ? i : cnt - 1u)];          // surplus lanes recompute the last sample (never stored)
-            // tile -> (n, tile row, tile column) with the host's reciprocals (exact for tile < 2^20, 1 < divisor < 2^12)
-            const uint32_t tile = sid >> 12;
-            const uint32_t q = a.tiles_x == 1 ? tile : __umulhi(tile, d.tx_magic), tcol = tile - q * (uint32_t)a.tiles_x;
-            const uint32_t n = a.tiles_y == 1 ? q : __umulhi(q, d.ty_magic), trow = q - n * (uint32_t)a.tiles_y;
-            const int y = a.oy0 + (int)trow * KB_TH + (int)((sid >> 6) & 15u), x = (int)tcol * KB_TW + (int)(sid & 63u);
-            const uint32_t off = (uint32_t)(view_addr(a.in, (int)n, (int)((sid >> 10) & 3u), y, x - 2) - a.in.p);
-            desc[s] = off | ((uint32_t)imin(y - ylo, 2) << 28) | ((uint32_t)imin(yhi - y, 2) << 30);
+            desc[s] = d.desc[first + (i < cnt ? i : cnt - 1u)];          // surplus lanes recompute the last sample (never stored)
         }
         SlabAcc acc[kSlabS];
 #pragma unroll
@@ -2698,7 +2889,7 @@ __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, Detail
             const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;     // scalar
             const uint8_t *pair = d.slab[m] + (size_t)h * kSlabPairBytes;
             SLAB_CLK(3);                   // item set-up / epilogue / stores
-            slab_mode(a, pat, pair, smem, desc, acc SLAB_CLK_PASS);
+            slab_mode(a, pat, cnt, pair, smem, desc, acc SLAB_CLK_PASS);
         }
 #pragma unroll
         for (int s = 0; s < kSlabS; ++s) {
@@ -2719,13 +2910,14 @@ __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, Detail
 
 template <int OUT>
 __global__ void __launch_bounds__(KB_TW *KB_TH) detail_retile_kernel(StageArgs a, DetailArgs d) {
-    const int tile = (int)blockIdx.x;
-    if (a.verdict[tile] != 1u) return;
+    const uint32_t ndet = d.ctl[kDetTiles];
+    const int tx = threadIdx.x % KB_TW, ty = threadIdx.x / KB_TW;
+    for (uint32_t li = blockIdx.x; li < ndet; li += gridDim.x) {
+    const int tile = (int)d.dlist[li];
     int n, y0, x0;
     decode_tile(a, tile, n, y0, x0, KB_TW, KB_TH);
-    const int tx = threadIdx.x % KB_TW, ty = threadIdx.x / KB_TW;
     const int y = y0 + ty, x = x0 + tx;
-    if (y >= a.oy1 || x >= a.W || x < kSlabXLo || x >= a.W - kSlabXHi) return;      // border columns: the fix-up kernel's
+    if (y >= a.oy1 || x >= a.W || x < kSlabXLo || x >= a.W - kSlabXHi) continue;      // border columns: the fix-up kernel's
     const uint32_t id = ((uint32_t)tile << 12) | (uint32_t)(ty << 6) | (uint32_t)tx;
     if constexpr (OUT == kOutPackedRGBU4) {
         const uint4 r = d.blocks[id], g = d.blocks[id | (1u << 10)], b = d.blocks[id | (2u << 10)];
@@ -2747,19 +2939,20 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) detail_retile_kernel(StageArgs a
             }
         }
     }
+    }
 }
 
 bool detail_slab_supported(const StageArgs &a) {
     const long long tiles = (long long)a.N * a.tiles_x * a.tiles_y;      // 64x16 verdict tiling
     const unsigned long long bytes = (unsigned long long)a.N * (unsigned long long)(a.in.sN < 0 ? -a.in.sN : a.in.sN);
-    return a.C <= 3 && a.M <= 3 && a.in.sX == 1 && tiles > 0 && tiles < (1ll << 20) && a.tiles_x < 4096 && a.tiles_y < 4096 &&
+    return a.C <= 3 && a.M <= 3 && a.in.sX == 1 && tiles > 0 && tiles < (1ll << 20) &&
            bytes < (1ull << 28) && (unsigned long long)a.N * a.H * a.W < (1ull << 32);
 }
 size_t detail_ids_count(const StageArgs &a) { return (size_t)a.N * a.tiles_x * a.tiles_y * 3 * KB_TW * KB_TH; }
-size_t detail_items_max(const StageArgs &a) { return detail_ids_count(a) / kSlabItem + 16; }
+size_t detail_items_max(const StageArgs &a) { return detail_ids_count(a) / kSlabItem + 16 + 8192; }      // + the small-item case of detail_plan_kernel (<= 2 x CUs x 4 items)
 size_t detail_blocks_count(const StageArgs &a) { return (size_t)a.N * a.tiles_x * a.tiles_y * 4096; }
 
-// the detailed tiles (a.verdict[tile] == 1) of a u == 4 final stage; d.ctl must be zeroed (64 dwords) ahead of this call
+// the detailed tiles (a.verdict[tile] == 1, histograms in d.thist from launch_tile_stat) of a u == 4 final stage
 hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_mode, int num_cus, hipStream_t st) {
     if (!detail_slab_supported(a) || !a.verdict || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
     static bool attr_set[64] = {};
@@ -2771,16 +2964,17 @@ hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_m
         attr_set[dev] = true;
     }
     const unsigned tiles = (unsigned)((long long)a.N * a.tiles_x * a.tiles_y);
-    DetailArgs dd = d;
-    dd.tx_magic = make_div_magic((uint32_t)a.tiles_x).magic;
-    dd.ty_magic = make_div_magic((uint32_t)a.tiles_y).magic;
-    hipLaunchKernelGGL(detail_bucket_kernel<false>, dim3(tiles), dim3(256), 0, st, a, d);
-    hipLaunchKernelGGL(detail_plan_kernel, dim3(1), dim3(1024), 0, st, d);
-    hipLaunchKernelGGL(detail_bucket_kernel<true>, dim3(tiles), dim3(256), 0, st, a, d);
-    hipLaunchKernelGGL(stage_slab_kernel, dim3((unsigned)num_cus), dim3(kSlabNT), (size_t)kSlabLdsBytes, st, a, dd);
-    if (out_mode == kOutPlanarU4) hipLaunchKernelGGL(detail_retile_kernel<kOutPlanarU4>, dim3(tiles), dim3(KB_TW * KB_TH), 0, st, a, d);
-    else if (out_mode == kOutPackedRGBU4 && a.C == 3) hipLaunchKernelGGL(detail_retile_kernel<kOutPackedRGBU4>, dim3(tiles), dim3(KB_TW * KB_TH), 0, st, a, d);
-    else hipLaunchKernelGGL(detail_retile_kernel<kOutGeneric>, dim3(tiles), dim3(KB_TW * KB_TH), 0, st, a, d);
+    const unsigned walk = tiles < (unsigned)(8 * num_cus) ? tiles : (unsigned)(8 * num_cus);      // workgroups walking the list of detailed tiles
+    hipLaunchKernelGGL(detail_plan_kernel, dim3(1), dim3(1024), 0, st, d, (const uint32_t *)a.verdict, tiles, (uint32_t)(2 * num_cus));
+    hipLaunchKernelGGL(detail_fill_kernel, dim3(tiles < 2 * walk ? tiles : 2 * walk), dim3(256), 0, st, a, d);
+    #if defined(MULUT_VARIANT_slablds64)
+    hipLaunchKernelGGL(stage_slab_kernel, dim3((unsigned)num_cus), dim3(kSlabNT), (size_t)65536, st, a, d);      // experiment: empty-launch cost against the LDS size (wrong results when there are items)
+#else
+    hipLaunchKernelGGL(stage_slab_kernel, dim3((unsigned)num_cus), dim3(kSlabNT), (size_t)kSlabLdsBytes, st, a, d);
+#endif
+    if (out_mode == kOutPlanarU4) hipLaunchKernelGGL(detail_retile_kernel<kOutPlanarU4>, dim3(walk), dim3(KB_TW * KB_TH), 0, st, a, d);
+    else if (out_mode == kOutPackedRGBU4 && a.C == 3) hipLaunchKernelGGL(detail_retile_kernel<kOutPackedRGBU4>, dim3(walk), dim3(KB_TW * KB_TH), 0, st, a, d);
+    else hipLaunchKernelGGL(detail_retile_kernel<kOutGeneric>, dim3(walk), dim3(KB_TW * KB_TH), 0, st, a, d);
     return hipGetLastError();
 }
 
