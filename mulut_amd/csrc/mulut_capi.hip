@@ -50,7 +50,7 @@ struct mulut_ctx {
     uint8_t *sflags = nullptr;     // site_flag_kernel's byte per pixel of the final-stage input
     size_t sflags_cap = 0;
     uint32_t *det_ctl = nullptr;   // detailed-tile path of the final stage (launch_detail_slab): counters, items, sample ids, blocks
-    uint32_t *det_items = nullptr, *det_ids = nullptr, *det_desc = nullptr, *det_tpos = nullptr, *det_dlist = nullptr;
+    uint32_t *det_items = nullptr, *det_desc = nullptr, *det_tpos = nullptr, *det_dlist = nullptr;
     uint16_t *det_thist = nullptr;
     uint4 *det_blocks = nullptr;
     size_t det_items_cap = 0, det_ids_cap = 0, det_blocks_cap = 0, det_tiles_cap = 0;
@@ -144,7 +144,6 @@ int mulut_destroy(mulut_ctx *ctx) {
     if (ctx->tlist) (void)hipFree(ctx->tlist);
     if (ctx->det_ctl) (void)hipFree(ctx->det_ctl);
     if (ctx->det_items) (void)hipFree(ctx->det_items);
-    if (ctx->det_ids) (void)hipFree(ctx->det_ids);
     if (ctx->det_desc) (void)hipFree(ctx->det_desc);
     if (ctx->det_thist) (void)hipFree(ctx->det_thist);
     if (ctx->det_tpos) (void)hipFree(ctx->det_tpos);
@@ -547,7 +546,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         if (slab) {
             DetailArgs d;
             memset(&d, 0, sizeof(d));
-            d.ctl = ctx->det_ctl; d.items = ctx->det_items; d.ids = ctx->det_ids; d.desc = ctx->det_desc; d.blocks = ctx->det_blocks;
+            d.ctl = ctx->det_ctl; d.items = ctx->det_items; d.desc = ctx->det_desc; d.blocks = ctx->det_blocks;
             d.thist = ctx->det_thist; d.tpos = ctx->det_tpos; d.dlist = ctx->det_dlist;
             for (int m = 0; m < 3; ++m) d.slab[m] = m < ctx->n_modes ? ctx->tab[stage - 1][pattern_id(ctx->modes[m])].slab : nullptr;
             HIP_TRY(ctx, launch_detail_slab(a, d, mode, ctx->num_cus, st));
@@ -645,11 +644,9 @@ static int ensure_detail(mulut_ctx *ctx, size_t tiles, size_t items, size_t ids,
         ctx->det_items_cap = items;
     }
     if (ids > ctx->det_ids_cap) {
-        if (ctx->det_ids) HIP_TRY(ctx, hipFree(ctx->det_ids));
         if (ctx->det_desc) HIP_TRY(ctx, hipFree(ctx->det_desc));
-        ctx->det_ids = ctx->det_desc = nullptr;
+        ctx->det_desc = nullptr;
         ctx->det_ids_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_ids, ids * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMalloc((void **)&ctx->det_desc, ids * sizeof(uint32_t)));
         ctx->det_ids_cap = ids;
     }
@@ -693,6 +690,7 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
                 StageArgs t;
                 memset(&t, 0, sizeof(t));
                 t.N = N; t.tiles_x = (W + tw - 1) / tw; t.tiles_y = (H + th - 1) / th;
+                t.in.sN = (long long)H * W * C;
                 if ((long long)t.N * t.tiles_x * t.tiles_y < (1ll << 20)) {
                     rc = ensure_detail(ctx, (size_t)t.N * t.tiles_x * t.tiles_y, detail_items_max(t), detail_ids_count(t), detail_blocks_count(t));
                     if (rc) return rc;

@@ -84,10 +84,9 @@ struct DetailArgs {
     uint16_t *thist;           // 16 per tile: anchor-MSB histogram of a detailed tile (tile_stat_kernel)
     uint32_t *tpos;            // 16 per tile: where the tile's samples of each anchor MSB start in ids / desc (detail_plan_kernel)
     uint32_t *dlist;           // the detailed tiles
-    uint32_t *items;           // two dwords per item: anchor MSB << 28 | samples, first index into ids
-    uint32_t *ids;             // sample ids (tile << 12 | c << 10 | ty << 6 | tx) grouped by anchor MSB
-    uint32_t *desc;            // per sample: byte offset of (n, c, y, x - 2) in the stage input | row clamps (stage_slab_kernel)
-    uint4 *blocks;             // finished 4x4 blocks (four packed rows), indexed by sample id
+    uint32_t *items;           // two dwords per item: anchor MSB << 28 | samples, first index into desc
+    uint32_t *desc;            // samples grouped by anchor MSB: byte offset of (n, c, y, x - 2) in the stage input | row clamps (stage_slab_kernel)
+    uint4 *blocks;             // finished 4x4 blocks (four packed rows), indexed by the sample's byte offset in the stage input
     const uint8_t *slab[3];    // per mode: the table as 16 slab pairs (mulut_core.h), kSlabTableBytes (+ 1 KiB of padding: the copy moves whole KiB)
 };
 

@@ -2644,7 +2644,6 @@ __global__ void __launch_bounds__(256) detail_fill_kernel(StageArgs a, DetailArg
             if (pos[k] != 0xFFFFFFFFu) {
                 const int s = (int)threadIdx.x + k * 256;
                 const int c = s >> 10, y = y0 + ((s >> 6) & 15), x = x0 + (s & 63);
-                d.ids[pos[k]] = ((uint32_t)tile << 12) | (uint32_t)s;
                 d.desc[pos[k]] = (uint32_t)(view_addr(a.in, n, c, y, x - 2) - a.in.p) | ((uint32_t)imin(y - ylo, 2) << 28) | ((uint32_t)imin(yhi - y, 2) << 30);
             }
     }
@@ -2898,7 +2897,7 @@ __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, Detail
             uint32_t o[4];
             tube_finish_rows(a, r, o);
             const uint32_t i = (uint32_t)s * kSlabNT + threadIdx.x;
-            if (i < cnt) d.blocks[d.ids[first + i]] = make_uint4(o[0], o[1], o[2], o[3]);
+            if (i < cnt) d.blocks[(desc[s] & 0x0FFFFFFFu) + 2u] = make_uint4(o[0], o[1], o[2], o[3]);      // indexed by the sample's byte offset in the stage input
         }
     }
 #if defined(MULUT_VARIANT_slabclk)   /* probe build: shader-clock ticks / 1024 of wave 0 of every workgroup per phase, summed into ctl[48..51] */
@@ -2918,14 +2917,14 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) detail_retile_kernel(StageArgs a
     decode_tile(a, tile, n, y0, x0, KB_TW, KB_TH);
     const int y = y0 + ty, x = x0 + tx;
     if (y >= a.oy1 || x >= a.W || x < kSlabXLo || x >= a.W - kSlabXHi) continue;      // border columns: the fix-up kernel's
-    const uint32_t id = ((uint32_t)tile << 12) | (uint32_t)(ty << 6) | (uint32_t)tx;
+    const size_t id = (size_t)(view_addr(a.in, n, 0, y, x) - a.in.p), cs = (size_t)a.in.sC;      // block index = byte offset in the stage input
     if constexpr (OUT == kOutPackedRGBU4) {
-        const uint4 r = d.blocks[id], g = d.blocks[id | (1u << 10)], b = d.blocks[id | (2u << 10)];
+        const uint4 r = d.blocks[id], g = d.blocks[id + cs], b = d.blocks[id + 2 * cs];
         const uint32_t oR[4] = {r.x, r.y, r.z, r.w}, oG[4] = {g.x, g.y, g.z, g.w}, oB[4] = {b.x, b.y, b.z, b.w};
         store_rgb<4>(a, n, y, x, oR, oG, oB);
     } else {
         for (int c = 0; c < a.C; ++c) {
-            const uint4 v = d.blocks[id | ((uint32_t)c << 10)];
+            const uint4 v = d.blocks[id + (size_t)c * cs];
             const uint32_t o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int sy = 0; sy < 4; ++sy) {
@@ -2950,7 +2949,7 @@ bool detail_slab_supported(const StageArgs &a) {
 }
 size_t detail_ids_count(const StageArgs &a) { return (size_t)a.N * a.tiles_x * a.tiles_y * 3 * KB_TW * KB_TH; }
 size_t detail_items_max(const StageArgs &a) { return detail_ids_count(a) / kSlabItem + 16 + 8192; }      // + the small-item case of detail_plan_kernel (<= 2 x CUs x 4 items)
-size_t detail_blocks_count(const StageArgs &a) { return (size_t)a.N * a.tiles_x * a.tiles_y * 4096; }
+size_t detail_blocks_count(const StageArgs &a) { return (size_t)a.N * (size_t)(a.in.sN < 0 ? -a.in.sN : a.in.sN); }      // one per byte of the stage input
 
 // the detailed tiles (a.verdict[tile] == 1, histograms in d.thist from launch_tile_stat) of a u == 4 final stage
 hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_mode, int num_cus, hipStream_t st) {
