@@ -426,6 +426,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     const bool last = stage == ctx->stages;
     const int u = stage_u(ctx, stage);
     a.in = in; a.out = out;
+    a.in_padded = (in.p == ctx->ws[0] || in.p == ctx->ws[1]) ? 1 : 0;
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.oy0 = oy0; a.oy1 = oy1;
     a.M = ctx->n_modes;
@@ -584,7 +585,7 @@ static int ensure_workspace(mulut_ctx *ctx, size_t bytes) {
         w = nullptr;
     }
     ctx->ws_bytes = 0;
-    for (auto &w : ctx->ws) HIP_TRY(ctx, hipMalloc((void **)&w, bytes));
+    for (auto &w : ctx->ws) HIP_TRY(ctx, hipMalloc((void **)&w, bytes + 64));      // + padding: kernels may read whole dwords / 8 bytes at the very end (StageArgs::in_padded)
     ctx->ws_bytes = bytes;
     return MULUT_OK;
 }

@@ -28,6 +28,7 @@ struct View {
 __host__ __device__ constexpr int row_dwords(int u) { return (u * u + 3) / 4; }
 
 struct StageArgs {
+    int in_padded;   // the input buffer is followed by >= 8 readable bytes (the context's workspace)
     View in, out;
     int N, C, H, W;         // logical (full-image) size of the stage input
     int oy0, oy1;           // LR rows whose outputs this launch produces
@@ -77,8 +78,13 @@ struct BandArgs {
 enum K2Out { kOutGeneric = 0, kOutPlanarU4 = 1, kOutPackedRGBU4 = 2 };
 
 // device buffers of the detailed-tile path of the final stage (launch_detail_slab)
-constexpr int kSlabXLo = 2, kSlabXHi = 6;      // pixels with x < 2 or x >= W - 6 take the pixel fix-up list (a window row is read as 8 bytes from column x - 2)
+// Pixels in the first 2 columns (and the last 2) need edge replication inside the 8 bytes a window row is read as (from
+// column x - 2) and take the pixel fix-up list; so do the 4 columns before those unless the stage input is followed by
+// readable padding (StageArgs::in_padded: the pipeline's own intermediate images are), because the 8 bytes of the image's
+// very last rows would otherwise end beyond the buffer.
+constexpr int kSlabXLo = 2, kSlabXHi = 6, kSlabXHiPadded = 2;
 constexpr int kDetCount = 0, kDetStart = 16, kDetTiles = 62, kDetItems = 63;      // dword offsets in DetailArgs::ctl
+__host__ __device__ inline int slab_x_hi(const StageArgs &a) { return a.in_padded ? kSlabXHiPadded : kSlabXHi; }
 struct DetailArgs {
     uint32_t *ctl;             // 64 dwords: [0..15] samples per anchor MSB, [16..31] list starts, [62] detailed tiles, [63] work items
     uint16_t *thist;           // 16 per tile: anchor-MSB histogram of a detailed tile (tile_stat_kernel)

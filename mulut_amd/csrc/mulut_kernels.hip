@@ -1111,7 +1111,7 @@ __global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *v
         for (int s = threadIdx.x; s < a.C * TH * TW; s += 256) {
             const int tx = s % TW, ty = (s / TW) % TH, c = s / (TW * TH);
             const int x = x0 + tx;
-            if (y0 + ty < a.oy1 && x < a.W && x >= kSlabXLo && x < a.W - kSlabXHi)
+            if (y0 + ty < a.oy1 && x < a.W && x >= kSlabXLo && x < a.W - slab_x_hi(a))
                 atomicAdd(&s_hist[s_h[c * (PH * PW) + (ty + kHalo) * PW + (tx + kHalo)]], 1u);
         }
         __syncthreads();
@@ -2622,7 +2622,7 @@ __global__ void __launch_bounds__(256) detail_fill_kernel(StageArgs a, DetailArg
             const int c = s >> 10, ty = (s >> 6) & 15, tx = s & 63;
             const int y = y0 + ty, x = x0 + tx;
             const bool inside = c < a.C && y < a.oy1 && x < a.W;
-            const bool slab = inside && x >= kSlabXLo && x < a.W - kSlabXHi;
+            const bool slab = inside && x >= kSlabXLo && x < a.W - slab_x_hi(a);
             pos[k] = 0xFFFFFFFFu;
             if (slab) {
                 const uint32_t h = (uint32_t)(*view_addr(a.in, n, c, y, x) >> 4);
@@ -2916,7 +2916,7 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) detail_retile_kernel(StageArgs a
     int n, y0, x0;
     decode_tile(a, tile, n, y0, x0, KB_TW, KB_TH);
     const int y = y0 + ty, x = x0 + tx;
-    if (y >= a.oy1 || x >= a.W || x < kSlabXLo || x >= a.W - kSlabXHi) continue;      // border columns: the fix-up kernel's
+    if (y >= a.oy1 || x >= a.W || x < kSlabXLo || x >= a.W - slab_x_hi(a)) continue;      // border columns: the fix-up kernel's
     const size_t id = (size_t)(view_addr(a.in, n, 0, y, x) - a.in.p), cs = (size_t)a.in.sC;      // block index = byte offset in the stage input
     if constexpr (OUT == kOutPackedRGBU4) {
         const uint4 r = d.blocks[id], g = d.blocks[id + cs], b = d.blocks[id + 2 * cs];
