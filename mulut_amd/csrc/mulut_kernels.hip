@@ -2828,9 +2828,10 @@ __device__ __forceinline__ void slab_sample(int pat, const SlabWin &w, SlabAcc &
 // one mode of one item: the slab pair into LDS (LDS-DMA: 154 pieces of 1 KiB, wave w takes pieces w, w + 16, ...), then the
 // mode's four passes of the thread's samples; the window of the next sample is in flight while the current one is computed,
 // the first one while the slab pair is copied
-__device__ __forceinline__ void slab_mode(const StageArgs &a, int pat, uint32_t cnt, const uint8_t *pair, uint8_t *smem, const uint32_t (&desc)[kSlabS], SlabAcc (&acc)[kSlabS] SLAB_CLK_ARGS) {
+__device__ __forceinline__ void slab_mode(const StageArgs &a, int pat, uint32_t cnt, const uint8_t *pair, bool in_lds, uint8_t *smem, const uint32_t (&desc)[kSlabS], SlabAcc (&acc)[kSlabS] SLAB_CLK_ARGS) {
     SlabWin wa, wb;
     slab_load_window(a, pat, desc[0], wa);
+    if (!in_lds) {                     // workgroup-uniform
     __syncthreads();                   // everyone is done with the previous slab pair
     SLAB_CLK(0);                       // waiting for the slowest wave of the previous mode
     {
@@ -2845,6 +2846,7 @@ __device__ __forceinline__ void slab_mode(const StageArgs &a, int pat, uint32_t 
         }
     }
     __syncthreads();
+    }
     SLAB_CLK(1);                       // slab pair copy
 #if defined(MULUT_VARIANT_slabnopf)
     static_for<0, kSlabS>([&](auto S) {
@@ -2871,6 +2873,8 @@ __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, Detail
 #if defined(MULUT_VARIANT_slabclk)
     unsigned long long clk[4] = {0, 0, 0, 0}, clk_last = __builtin_amdgcn_s_memtime();
 #endif
+    const uint8_t *resident = nullptr;      // the slab pair in LDS
+    bool snake = false;
     for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {
         const uint32_t hdr = d.items[2 * it], first = d.items[2 * it + 1];
         const uint32_t h = hdr >> 28, cnt = hdr & 0x0FFFFFFFu;
@@ -2883,13 +2887,17 @@ __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, Detail
         SlabAcc acc[kSlabS];
 #pragma unroll
         for (int s = 0; s < kSlabS; ++s) acc[s].clear();
+        // the modes in alternating order from item to item: consecutive items of a workgroup mostly share their anchor, and
+        // the pair the last mode left in LDS then serves the next item's first mode (the sums do not depend on the order)
         for (int mv = 0; mv < a.M; ++mv) {
-            const int m = __builtin_amdgcn_readfirstlane(mv);
+            const int m = __builtin_amdgcn_readfirstlane(snake ? a.M - 1 - mv : mv);
             const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;     // scalar
             const uint8_t *pair = d.slab[m] + (size_t)h * kSlabPairBytes;
             SLAB_CLK(3);                   // item set-up / epilogue / stores
-            slab_mode(a, pat, cnt, pair, smem, desc, acc SLAB_CLK_PASS);
+            slab_mode(a, pat, cnt, pair, pair == resident, smem, desc, acc SLAB_CLK_PASS);
+            resident = pair;
         }
+        snake = !snake;
 #pragma unroll
         for (int s = 0; s < kSlabS; ++s) {
             RotAcc<4> r;
