@@ -505,9 +505,9 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     }
     const bool x = ctx->final_kernel != 2;   // compact band only on request
     if (tube) {
-        // every pixel of the launch may end up on the fix-up list (ids are 32-bit: larger launches take the band-x kernel)
-        if ((unsigned long long)N * H * W >= (1ull << 32)) return MULUT_EUNSUPPORTED;
-        rc = ensure_fix(ctx, (size_t)N * (oy1 - oy0) * W);
+        // every sample of the launch may end up on the fix-up list (entries: 30-bit pixel id + channel)
+        if ((unsigned long long)N * H * W >= (1ull << 30)) return MULUT_EUNSUPPORTED;
+        rc = ensure_fix(ctx, (size_t)N * (oy1 - oy0) * W * 3);
         if (rc) return rc;
         a.fix_count = ctx->fix;
         a.fix_list = ctx->fix + 16;
@@ -682,7 +682,7 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
         if (rc) return rc;
         if (ctx->n_modes <= 3) {
             const bool u1 = ctx->stages > 1 || ctx->scale == 1;
-            rc = ensure_fix(ctx, (size_t)N * H * W * ((u1 || ctx->scale == 2) ? (size_t)C : 1));
+            rc = ensure_fix(ctx, (size_t)N * H * W * ((u1 || ctx->scale == 2 || ctx->scale == 4) ? (size_t)(C > 3 ? C : 3) : 1));
             if (rc) return rc;
             if (ctx->scale == 4) {
                 rc = ensure_sflags(ctx, (size_t)N * H * W);
@@ -871,7 +871,8 @@ const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
         return ctx->final_kernel == 2 ? stage_band_name(kOutPackedRGBU4)
                : ctx->final_kernel == 3 ? stage_bandx_name(kOutPackedRGBU4)
                : ctx->final_kernel == 5 ? stage_tube_name(kOutPackedRGBU4)
-               : (ctx->final_kernel == 6 || ctx->final_kernel == 0) ? "hybrid: tile_stat_kernel + stage_tube_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)"
+               : (ctx->final_kernel == 6 || ctx->final_kernel == 0) ? (ctx->detail_kernel == 0 ? "hybrid: tile_stat_kernel + stage_tube_kernel<rgb> (smooth tiles) + stage_slab_kernel (detailed tiles, anchor slabs in LDS)"
+                                           : "hybrid: tile_stat_kernel + stage_tube_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)")
                                         : "hybrid: tile_stat_kernel + stage_bandx_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)";
     return stage_up_name(ctx->scale, ctx->scale == 4 ? kOutPackedRGBU4 : kOutGeneric);
 }

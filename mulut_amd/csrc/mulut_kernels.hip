@@ -2257,10 +2257,12 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
             uint32_t o0[4], o1[4], o2[4];     // packed output rows of the finished channels (RGB path)
 #pragma unroll
             for (int k = 0; k < 4; ++k) o0[k] = o1[k] = o2[k] = 0;
-            // != 0: some pass of this pixel may have left the tube (FLAGGED: site_flag_kernel's byte for the pixel)
-            uint32_t dirty = FLAGGED ? (uint32_t)a.site_flags[((size_t)n * a.H + y) * a.W + x] : 0u;
+            // per channel: != 0 when some pass of the sample may have left the tube (FLAGGED: bit c of site_flag_kernel's byte)
+            const uint32_t sflags = FLAGGED ? (uint32_t)a.site_flags[((size_t)n * a.H + y) * a.W + x] : 0u;
+            const uint32_t pixel_id = (uint32_t)((n * a.H + y) * a.W + x);
 #pragma clang loop unroll(disable)
             for (int c = 0; c < a.C; ++c, win += 2 * PH * PW) {
+                uint32_t dirty = FLAGGED ? ((sflags >> c) & 1u) : 0u;
                 const uint32_t ca = *(const uint16_t *)(smem + win + 2 * (2 * PW + 2));
                 const uint32_t k0 = tube_anchor_key(ca), ha16 = tube_anchor_h16(ca), ha27 = pk_mad(ha16, pk_dup(kTubeSA), 0u);
                 RotAcc<4> acc;
@@ -2280,17 +2282,17 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
                     uint32_t o[4];
                     finish_channel<4, OUT>(a, acc, n, c, y, x, o);
                 }
+                // dirty samples (pixel, channel) go on the fix-up list: one atomic per wave (rare), compacted by lane rank
+                const unsigned long long dm = __ballot(dirty != 0u);
+                if (dm != 0ull) {
+                    const int lane = (int)(threadIdx.x & 63);
+                    uint32_t at = 0;
+                    if (lane == __ffsll((long long)dm) - 1) at = atomicAdd(a.fix_count, (uint32_t)__popcll(dm));
+                    at = (uint32_t)__shfl((int)at, __ffsll((long long)dm) - 1);
+                    if (dirty != 0u) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = pixel_id | ((uint32_t)c << 30);
+                }
             }
             if constexpr (OUT == kOutPackedRGBU4) store_rgb<4>(a, n, y, x, o0, o1, o2);
-            // dirty pixels go on the fix-up list: one atomic per wave (rare), compacted by lane rank
-            const unsigned long long dm = __ballot(dirty != 0u);
-            if (dm != 0ull) {
-                const int lane = (int)(threadIdx.x & 63);
-                uint32_t at = 0;
-                if (lane == __ffsll((long long)dm) - 1) at = atomicAdd(a.fix_count, (uint32_t)__popcll(dm));
-                at = (uint32_t)__shfl((int)at, __ffsll((long long)dm) - 1);
-                if (dirty != 0u) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)((n * a.H + y) * a.W + x);
-            }
         }
         if (nxt < last) stash(nxt, (it + 1) & 1, pix);
         __syncthreads();     // next tile published; everyone is done reading the current one
@@ -2310,10 +2312,11 @@ __global__ void __launch_bounds__(256) stage_up_fix_kernel(StageArgs a) {
     const uint32_t count = *a.fix_count;
     const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
-        const uint32_t id = a.fix_list[i];
+        // entry: pixel id (n H + y) W + x in the low 30 bits, channel in the top two (3 = every channel)
+        const uint32_t ent = a.fix_list[i], id = ent & 0x3FFFFFFFu, only = ent >> 30;
         const int x = (int)(id % (uint32_t)a.W), y = (int)((id / (uint32_t)a.W) % (uint32_t)a.H), n = (int)(id / ((uint32_t)a.W * (uint32_t)a.H));
-        uint32_t oR[4], oG[4], oB[4];
         for (int c = 0; c < a.C; ++c) {
+            if (only != 3u && (uint32_t)c != only) continue;
             auto px = [&](int dy, int dx) {
                 const int gy = imin(imax(y + dy, ylo), yhi), gx = imin(imax(x + dx, 0), a.W - 1);
                 return (int)*view_addr(a.in, n, c, gy, gx);
@@ -2337,9 +2340,15 @@ __global__ void __launch_bounds__(256) stage_up_fix_kernel(StageArgs a) {
             }
             uint32_t o[4];
             finish_channel<4, OUT>(a, acc, n, c, y, x, o);
-            if constexpr (OUT == kOutPackedRGBU4) keep_rgb<4>(c, o, oR, oG, oB);
+            if constexpr (OUT == kOutPackedRGBU4) {      // one channel of the packed RGB block: bytes at stride 3
+#pragma unroll
+                for (int sy = 0; sy < 4; ++sy) {
+                    uint8_t *dst = const_cast<uint8_t *>(view_addr(a.out, n, 0, y * 4 + sy, x * 4)) + c;
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) dst[3 * sx] = (uint8_t)(o[sy] >> (8 * sx));
+                }
+            }
         }
-        if constexpr (OUT == kOutPackedRGBU4) store_rgb<4>(a, n, y, x, oR, oG, oB);
     }
 }
 
@@ -2486,12 +2495,18 @@ __global__ void __launch_bounds__(1024) detail_plan_kernel(DetailArgs d, const u
         // chunks of 8 tiles per thread, fully unrolled: all 24 loads of a chunk are in flight together (a rolled loop makes a
         // round trip to L2 per iteration, and this is one workgroup)
         for (uint32_t base = 0; base < ntiles; base += 8 * 1024) {
-            uint32_t det[8];
+            uint32_t det[8], any = 0;
             uint4 r[8][2];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x, tc = t < ntiles ? t : ntiles - 1u;
                 det[k] = (t < ntiles && verdict[tc] == 1u) ? 1u : 0u;
+                any |= det[k];
+            }
+            if (!__any((int)any)) continue;           // smooth content: no histogram is read at all
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x, tc = t < ntiles ? t : ntiles - 1u;
                 r[k][0] = half[0][tc];
                 r[k][1] = half[1][tc];
             }
@@ -2637,7 +2652,7 @@ __global__ void __launch_bounds__(256) detail_fill_kernel(StageArgs a, DetailArg
         for (int k = 0; k < 4; ++k)
             if (fixr[k] != 0xFFFFFFFFu) {
                 const int s = (int)threadIdx.x + k * 256;
-                a.fix_list[s_fix[1] + fixr[k]] = (uint32_t)((n * a.H + y0 + ((s >> 6) & 15)) * a.W + x0 + (s & 63));
+                a.fix_list[s_fix[1] + fixr[k]] = (uint32_t)((n * a.H + y0 + ((s >> 6) & 15)) * a.W + x0 + (s & 63)) | (3u << 30);
             }
 #pragma unroll
         for (int k = 0; k < PER; ++k)

@@ -373,6 +373,42 @@ def test_randomised_configurations_vs_oracle():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 129, 3), (1, 150, 200, 3), (2, 16, 64, 1), (1, 33, 70, 2), (1, 5, 9, 3)])
+def test_detailed_tiles_take_the_anchor_slab_path(shape):
+    """Noisy content goes through the anchor-slab kernels of the final stage (the work counters say so), gives the oracle's
+    bytes for random and extreme tables in both layouts and in strips, the same bytes as the full-table gather kernel, and the
+    same bytes again when repeated (the id lists are built without atomics)."""
+    rng = np.random.default_rng(shape[1] * 1000 + shape[2])
+    n, h, w, c = shape
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    img[:, :, : w // 3] = (img[:, :, : w // 3] // 64) + 100            # a smooth part too: both final-stage kernels run
+    for val in (None, 127, -128):
+        luts = {}
+        for st in (1, 2):
+            for m in "sdy":
+                vn = 16 if st == 2 else 1
+                luts["s%d_%s" % (st, m)] = (np.full((17 ** 4, vn), val, np.int8) if val is not None
+                                             else rng.integers(-128, 128, (17 ** 4, vn), dtype=np.int8))
+        want = np.stack([c_oracle.pipeline(luts, 2, "sdy", 4, im) for im in img])
+        e = MuLUTEngine(0).configure(2, "sdy", 4, 4).set_lut_dict(luts)
+        got = e.pipeline(dev(img))
+        cnt = e.last_detail_counters()
+        assert np.array_equal(got.cpu().numpy(), want), val
+        if val is None and w >= 64:
+            assert sum(cnt["samples_per_anchor"]) > 0 and cnt["items"] > 0, cnt        # the slab path did run
+        assert torch.equal(e.pipeline(dev(img)), got)                                    # deterministic
+        chw = e.pipeline(dev(np.ascontiguousarray(img.transpose(0, 3, 1, 2))), layout=LAYOUT_CHW)
+        assert np.array_equal(chw.cpu().numpy().transpose(0, 2, 3, 1), want), val
+        if h >= 8:                                                                         # two strips of the first image
+            mid, halo = h // 2, e.halo
+            top = e.pipeline_rows(dev(img[0][: min(h, mid + halo)]), 0, 0, mid, h, layout=LAYOUT_HWC)
+            bot = e.pipeline_rows(dev(img[0][max(0, mid - halo):]), max(0, mid - halo), mid, h, h, layout=LAYOUT_HWC)
+            assert np.array_equal(torch.cat([top, bot], 0).cpu().numpy(), want[0]), val
+        e.set_tuning("detail_kernel", 1)
+        assert torch.equal(e.pipeline(dev(img)), got)
+        e.close()
+
+
 @pytest.mark.parametrize("modes", ["sdysd", "sdysdysd"])
 def test_more_than_four_modes_at_scale_4(modes):
     """scale 4 with 5 and 8 modes: per-rotation accumulators (the merged pairs hold 4 x 16 x 255 per field at most),

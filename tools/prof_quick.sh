@@ -1,6 +1,6 @@
 #!/bin/bash
 # Quick rocprofv3 passes over the C++ C-ABI harness (tools/cabi_bench.cpp: starts in a second, no Python).
-#   usage: tools/prof_quick.sh <tag> "<cabi_bench args>" [stats|sq|lds|mem ...]
+#   usage: tools/prof_quick.sh <tag> "<cabi_bench args>" [stats|sq|lds|mem|ta|ta2 ...]
 # stats = --kernel-trace --stats; the others are one --pmc pass each (never mixed with tracing).  Results under
 # gpurun_out/pq_<tag>/ ; a one-line-per-counter summary is printed.
 set -u
@@ -17,6 +17,8 @@ for P in "$@"; do
     sq)    C="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" ;;
     lds)   C="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" ;;
     mem)   C="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum" ;;
+    ta)    C="TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUFFER_WAVEFRONTS_sum" ;;
+    ta2)   C="TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" ;;
     *) echo "unknown pass $P"; continue ;;
   esac
   if [ "$P" != stats ]; then
