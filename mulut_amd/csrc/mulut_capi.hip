@@ -45,7 +45,8 @@ struct mulut_ctx {
     float epi_c = 0.0f;
     uint32_t *verdict = nullptr;   // per-tile smooth/detailed verdicts of the hybrid final stage
     size_t verdict_tiles = 0;
-    uint32_t *fix = nullptr;       // [0] = count, [16...] = pixel ids of the tube kernel's fix-up list
+    uint32_t *fix = nullptr;       // [0] = count, [16...] = entries of the fix-up list (samples recomputed from the full tables)
+    uint32_t *dirty = nullptr;     // same shape: the tube kernel's dirty samples when the anchor-slab path takes them
     size_t fix_cap = 0;            // capacity in ids
     uint8_t *sflags = nullptr;     // site_flag_kernel's byte per pixel of the final-stage input
     size_t sflags_cap = 0;
@@ -54,6 +55,9 @@ struct mulut_ctx {
     uint16_t *det_thist = nullptr;
     uint4 *det_blocks = nullptr;
     size_t det_items_cap = 0, det_ids_cap = 0, det_blocks_cap = 0, det_tiles_cap = 0;
+    int dirty_to_slab = 0;         // tuning "dirty_to_slab": 1 = the tube kernel's dirty samples are computed by the anchor-slab kernels, 0 = by the fix-up kernel
+                                   // (measured on D-natural, 0.9 % dirty samples: 244 vs 226 us/frame -- the extra items cost the slab kernel a second
+                                   // round of ~50 us, more than the gathers of the fix-up kernel; kept as an option)
     int detail_kernel = 0;         // tuning "detail_kernel": 0 = anchor slabs in LDS (when the launch qualifies), 1 = full-table gather kernel
     int site_flags_on = 0;         // tuning "tube_site_flags": 1 = flags from site_flag_kernel (no per-pass test in the tube kernel: 4 % fewer
                                    // cycles there, but the conservative 5x5 flags grow the fix-up list and the hybrid gains nothing), 0 = per-pass tests
@@ -140,6 +144,7 @@ int mulut_destroy(mulut_ctx *ctx) {
         if (w) (void)hipFree(w);
     if (ctx->verdict) (void)hipFree(ctx->verdict);
     if (ctx->fix) (void)hipFree(ctx->fix);
+    if (ctx->dirty) (void)hipFree(ctx->dirty);
     if (ctx->sflags) (void)hipFree(ctx->sflags);
     if (ctx->tlist) (void)hipFree(ctx->tlist);
     if (ctx->det_ctl) (void)hipFree(ctx->det_ctl);
@@ -542,13 +547,23 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.vt_x = a.tiles_x;
         a.vt_y = a.tiles_y;
         a.verdict_take = 0;
-        if (tube) MAIN_KERNEL(ctx, stage, st, launch_stage_tube(a, b, mode, ctx->num_cus, st));
+        if (tube && slab && ctx->dirty_to_slab) {
+            // the tube kernel's dirty samples go on their own list: the anchor-slab kernels compute them with the detailed tiles
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dirty, 0, sizeof(uint32_t), st));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->det_ctl, 0, kDetCtlDwords * sizeof(uint32_t), st));
+            StageArgs t = a;
+            t.fix_count = ctx->dirty;
+            t.fix_list = ctx->dirty + 16;
+            MAIN_KERNEL(ctx, stage, st, launch_stage_tube(t, b, mode, ctx->num_cus, st));
+        } else if (tube) MAIN_KERNEL(ctx, stage, st, launch_stage_tube(a, b, mode, ctx->num_cus, st));
         else MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
         if (slab) {
             DetailArgs d;
             memset(&d, 0, sizeof(d));
             d.ctl = ctx->det_ctl; d.items = ctx->det_items; d.desc = ctx->det_desc; d.blocks = ctx->det_blocks;
             d.thist = ctx->det_thist; d.tpos = ctx->det_tpos; d.dlist = ctx->det_dlist;
+            if (ctx->dirty_to_slab) { d.dirty_count = ctx->dirty; d.dirty_list = ctx->dirty + 16; }
+            else HIP_TRY(ctx, hipMemsetAsync(ctx->det_ctl, 0, kDetCtlDwords * sizeof(uint32_t), st));
             for (int m = 0; m < 3; ++m) d.slab[m] = m < ctx->n_modes ? ctx->tab[stage - 1][pattern_id(ctx->modes[m])].slab : nullptr;
             HIP_TRY(ctx, launch_detail_slab(a, d, mode, ctx->num_cus, st));
             HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
@@ -593,9 +608,11 @@ static int ensure_workspace(mulut_ctx *ctx, size_t bytes) {
 static int ensure_fix(mulut_ctx *ctx, size_t ids) {
     if (ids <= ctx->fix_cap) return MULUT_OK;
     if (ctx->fix) HIP_TRY(ctx, hipFree(ctx->fix));
-    ctx->fix = nullptr;
+    if (ctx->dirty) HIP_TRY(ctx, hipFree(ctx->dirty));
+    ctx->fix = ctx->dirty = nullptr;
     ctx->fix_cap = 0;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->fix, (ids + 16) * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->dirty, (ids + 16) * sizeof(uint32_t)));
     ctx->fix_cap = ids;
     return MULUT_OK;
 }
@@ -622,8 +639,8 @@ static int ensure_tlist(mulut_ctx *ctx, size_t tiles) {
 
 static int ensure_detail(mulut_ctx *ctx, size_t tiles, size_t items, size_t ids, size_t blocks) {
     if (!ctx->det_ctl) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_ctl, 64 * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMemset(ctx->det_ctl, 0, 64 * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->det_ctl, kDetCtlDwords * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemset(ctx->det_ctl, 0, kDetCtlDwords * sizeof(uint32_t)));
     }
     if (tiles > ctx->det_tiles_cap) {
         if (ctx->det_thist) HIP_TRY(ctx, hipFree(ctx->det_thist));
@@ -811,7 +828,7 @@ int mulut_last_detail_counters(mulut_ctx *ctx, uint32_t *out, int cap, void *str
     if (!ctx || !out || cap <= 0) return MULUT_EINVAL;
     if (!ctx->det_ctl || !ctx->fix) return 0;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint32_t ctl[64], fixn = 0;
+    uint32_t ctl[kDetCtlDwords], fixn = 0;
     HIP_TRY(ctx, hipMemcpyAsync(ctl, ctx->det_ctl, sizeof(ctl), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(ctx, hipMemcpyAsync(&fixn, ctx->fix, sizeof(fixn), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
@@ -833,6 +850,11 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "first_stage_kernel")) {
         if (value < 0 || value > 3) return MULUT_EINVAL;
         ctx->first_kernel = value;
+        return MULUT_OK;
+    }
+    if (!strcmp(key, "dirty_to_slab")) {
+        if (value < 0 || value > 1) return MULUT_EINVAL;
+        ctx->dirty_to_slab = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "detail_kernel")) {     // final-stage tiles the statistic marks detailed: 0 anchor slabs in LDS, 1 full-table gathers

@@ -83,10 +83,12 @@ enum K2Out { kOutGeneric = 0, kOutPlanarU4 = 1, kOutPackedRGBU4 = 2 };
 // readable padding (StageArgs::in_padded: the pipeline's own intermediate images are), because the 8 bytes of the image's
 // very last rows would otherwise end beyond the buffer.
 constexpr int kSlabXLo = 2, kSlabXHi = 6, kSlabXHiPadded = 2;
-constexpr int kDetCount = 0, kDetStart = 16, kDetTiles = 62, kDetItems = 63;      // dword offsets in DetailArgs::ctl
+constexpr int kDetCount = 0, kDetStart = 16, kDetDirty = 32, kDetTiles = 62, kDetItems = 63, kDetDirtyCursor = 64, kDetDirtyBase = 80, kDetCtlDwords = 128;      // dword offsets in DetailArgs::ctl
 __host__ __device__ inline int slab_x_hi(const StageArgs &a) { return a.in_padded ? kSlabXHiPadded : kSlabXHi; }
 struct DetailArgs {
-    uint32_t *ctl;             // 64 dwords: [0..15] samples per anchor MSB, [16..31] list starts, [62] detailed tiles, [63] work items
+    uint32_t *ctl;             // kDetCtlDwords: [0..15] samples per anchor MSB, [16..31] list starts, [32..47] dirty samples per anchor MSB (zero on entry),
+                               // [62] detailed tiles, [63] work items, [64..79] dirty cursors (zero on entry), [80..95] where the dirty samples start
+    uint32_t *dirty_count, *dirty_list;   // optional: the tube kernel's dirty samples (pixel id | channel << 30), to be computed here too
     uint16_t *thist;           // 16 per tile: anchor-MSB histogram of a detailed tile (tile_stat_kernel)
     uint32_t *tpos;            // 16 per tile: where the tile's samples of each anchor MSB start in ids / desc (detail_plan_kernel)
     uint32_t *dlist;           // the detailed tiles

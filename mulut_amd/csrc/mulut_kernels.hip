@@ -2545,15 +2545,17 @@ __global__ void __launch_bounds__(1024) detail_plan_kernel(DetailArgs d, const u
         // item size: whole items (4 samples per thread) when there is work for every workgroup, else fewer samples per thread
         // (a multiple of the workgroup size) so that the few samples still spread over the workgroups
         uint32_t total = 0;
-        for (int b = 0; b < 16; ++b) total += s_start[b];
+        for (int b = 0; b < 16; ++b) total += s_start[b] + d.ctl[kDetDirty + b];
         uint32_t isz = ((total / (want_items ? want_items : 1u) + kSlabNT - 1) / kSlabNT) * kSlabNT;
         isz = isz < (uint32_t)kSlabNT ? (uint32_t)kSlabNT : isz > (uint32_t)kSlabItem ? (uint32_t)kSlabItem : isz;
         s_isz = isz;
         uint32_t start = 0, item0 = 0;
         for (int b = 0; b < 16; ++b) {
-            const uint32_t cnt = s_start[b];
+            // the list of anchor MSB b: the samples of the detailed tiles, then the tube kernel's dirty samples
+            const uint32_t cnt = s_start[b] + d.ctl[kDetDirty + b];
             d.ctl[kDetCount + b] = cnt;
             d.ctl[kDetStart + b] = start;
+            d.ctl[kDetDirtyBase + b] = start + s_start[b];
             s_start[b] = start;
             s_item0[b] = item0;
             start += cnt;
@@ -2661,6 +2663,82 @@ __global__ void __launch_bounds__(256) detail_fill_kernel(StageArgs a, DetailArg
                 const int c = s >> 10, y = y0 + ((s >> 6) & 15), x = x0 + (s & 63);
                 d.desc[pos[k]] = (uint32_t)(view_addr(a.in, n, c, y, x - 2) - a.in.p) | ((uint32_t)imin(y - ylo, 2) << 28) | ((uint32_t)imin(yhi - y, 2) << 30);
             }
+    }
+}
+
+// The tube kernel's dirty samples (d.dirty_list: pixel id | channel << 30; their passes left the tube) join the lists of the
+// anchor-slab kernel instead of being recomputed by gathers from the full tables:
+//   dirty_count_kernel    samples per anchor MSB (LDS histogram per workgroup, 16 atomics per workgroup) -> ctl[kDetDirty..]
+//   detail_plan_kernel    reserves their places behind the detailed tiles' samples of the same anchor   -> ctl[kDetDirtyBase..]
+//   dirty_scatter_kernel  writes their descriptors there (rank from an LDS counter + one atomic per workgroup, round and anchor)
+//   dirty_retile_kernel   stores each finished block's channel into the output image
+// Samples in the image's border columns go to the pixel fix-up list (a.fix_list), as those of the detailed tiles do.
+__device__ __forceinline__ void dirty_decode(const StageArgs &a, uint32_t ent, int &n, int &c, int &y, int &x) {
+    const uint32_t id = ent & 0x3FFFFFFFu;
+    c = (int)(ent >> 30);
+    x = (int)(id % (uint32_t)a.W);
+    y = (int)((id / (uint32_t)a.W) % (uint32_t)a.H);
+    n = (int)(id / ((uint32_t)a.W * (uint32_t)a.H));
+}
+__global__ void __launch_bounds__(256) dirty_count_kernel(StageArgs a, DetailArgs d) {
+    __shared__ uint32_t s_hist[16];
+    if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t count = *d.dirty_count;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        int n, c, y, x;
+        dirty_decode(a, d.dirty_list[i], n, c, y, x);
+        if (x >= kSlabXLo && x < a.W - slab_x_hi(a)) atomicAdd(&s_hist[*view_addr(a.in, n, c, y, x) >> 4], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && s_hist[threadIdx.x]) atomicAdd(&d.ctl[kDetDirty + threadIdx.x], s_hist[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) dirty_scatter_kernel(StageArgs a, DetailArgs d) {
+    __shared__ uint32_t s_cnt[16], s_base[16];
+    const uint32_t count = *d.dirty_count;
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    for (uint32_t i0 = blockIdx.x * 256u; i0 < count; i0 += gridDim.x * 256u) {      // workgroup-uniform rounds
+        __syncthreads();
+        if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t h = 16, rank = 0, desc = 0;
+        if (i < count) {
+            const uint32_t ent = d.dirty_list[i];
+            int n, c, y, x;
+            dirty_decode(a, ent, n, c, y, x);
+            if (x >= kSlabXLo && x < a.W - slab_x_hi(a)) {
+                h = (uint32_t)(*view_addr(a.in, n, c, y, x) >> 4);
+                rank = atomicAdd(&s_cnt[h], 1u);
+                desc = (uint32_t)(view_addr(a.in, n, c, y, x - 2) - a.in.p) | ((uint32_t)imin(y - ylo, 2) << 28) | ((uint32_t)imin(yhi - y, 2) << 30);
+            } else {
+                a.fix_list[atomicAdd(a.fix_count, 1u)] = ent;          // border column (rare)
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) s_base[threadIdx.x] = d.ctl[kDetDirtyBase + threadIdx.x] + (s_cnt[threadIdx.x] ? atomicAdd(&d.ctl[kDetDirtyCursor + threadIdx.x], s_cnt[threadIdx.x]) : 0u);
+        __syncthreads();
+        if (h < 16) d.desc[s_base[h] + rank] = desc;
+    }
+}
+template <int OUT>
+__global__ void __launch_bounds__(256) dirty_retile_kernel(StageArgs a, DetailArgs d) {
+    const uint32_t count = *d.dirty_count;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        int n, c, y, x;
+        dirty_decode(a, d.dirty_list[i], n, c, y, x);
+        if (x < kSlabXLo || x >= a.W - slab_x_hi(a)) continue;
+        const uint4 v = d.blocks[(size_t)(view_addr(a.in, n, c, y, x) - a.in.p)];
+        const uint32_t o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int sy = 0; sy < 4; ++sy) {
+            if constexpr (OUT == kOutPlanarU4) {
+                *(uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n, c, y * 4 + sy, x * 4)) = o[sy];
+            } else {
+#pragma unroll
+                for (int sx = 0; sx < 4; ++sx) *const_cast<uint8_t *>(view_addr(a.out, n, c, y * 4 + sy, x * 4 + sx)) = (uint8_t)(o[sy] >> (8 * sx));
+            }
+        }
     }
 }
 
@@ -2987,8 +3065,11 @@ hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_m
     }
     const unsigned tiles = (unsigned)((long long)a.N * a.tiles_x * a.tiles_y);
     const unsigned walk = tiles < (unsigned)(8 * num_cus) ? tiles : (unsigned)(8 * num_cus);      // workgroups walking the list of detailed tiles
+    const bool dirty = d.dirty_list != nullptr;          // the tube kernel's dirty samples join the lists (d.ctl zeroed by the caller)
+    if (dirty) hipLaunchKernelGGL(dirty_count_kernel, dim3((unsigned)num_cus), dim3(256), 0, st, a, d);
     hipLaunchKernelGGL(detail_plan_kernel, dim3(1), dim3(1024), 0, st, d, (const uint32_t *)a.verdict, tiles, (uint32_t)(2 * num_cus));
     hipLaunchKernelGGL(detail_fill_kernel, dim3(tiles < 2 * walk ? tiles : 2 * walk), dim3(256), 0, st, a, d);
+    if (dirty) hipLaunchKernelGGL(dirty_scatter_kernel, dim3((unsigned)num_cus), dim3(256), 0, st, a, d);
     #if defined(MULUT_VARIANT_slablds64)
     hipLaunchKernelGGL(stage_slab_kernel, dim3((unsigned)num_cus), dim3(kSlabNT), (size_t)65536, st, a, d);      // experiment: empty-launch cost against the LDS size (wrong results when there are items)
 #else
@@ -2997,6 +3078,10 @@ hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_m
     if (out_mode == kOutPlanarU4) hipLaunchKernelGGL(detail_retile_kernel<kOutPlanarU4>, dim3(walk), dim3(KB_TW * KB_TH), 0, st, a, d);
     else if (out_mode == kOutPackedRGBU4 && a.C == 3) hipLaunchKernelGGL(detail_retile_kernel<kOutPackedRGBU4>, dim3(walk), dim3(KB_TW * KB_TH), 0, st, a, d);
     else hipLaunchKernelGGL(detail_retile_kernel<kOutGeneric>, dim3(walk), dim3(KB_TW * KB_TH), 0, st, a, d);
+    if (dirty) {
+        if (out_mode == kOutPlanarU4) hipLaunchKernelGGL(dirty_retile_kernel<kOutPlanarU4>, dim3((unsigned)(2 * num_cus)), dim3(256), 0, st, a, d);
+        else hipLaunchKernelGGL(dirty_retile_kernel<kOutGeneric>, dim3((unsigned)(2 * num_cus)), dim3(256), 0, st, a, d);
+    }
     return hipGetLastError();
 }
 
