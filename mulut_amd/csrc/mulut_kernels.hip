@@ -3067,7 +3067,7 @@ hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_m
     const unsigned walk = tiles < (unsigned)(8 * num_cus) ? tiles : (unsigned)(8 * num_cus);      // workgroups walking the list of detailed tiles
     const bool dirty = d.dirty_list != nullptr;          // the tube kernel's dirty samples join the lists (d.ctl zeroed by the caller)
     if (dirty) hipLaunchKernelGGL(dirty_count_kernel, dim3((unsigned)num_cus), dim3(256), 0, st, a, d);
-    hipLaunchKernelGGL(detail_plan_kernel, dim3(1), dim3(1024), 0, st, d, (const uint32_t *)a.verdict, tiles, (uint32_t)(2 * num_cus));
+    hipLaunchKernelGGL(detail_plan_kernel, dim3(1), dim3(1024), 0, st, d, (const uint32_t *)a.verdict, tiles, (uint32_t)num_cus);      // few samples: about one item per workgroup (an item's three slab copies make a second round dearer than longer items)
     hipLaunchKernelGGL(detail_fill_kernel, dim3(tiles < 2 * walk ? tiles : 2 * walk), dim3(256), 0, st, a, d);
     if (dirty) hipLaunchKernelGGL(dirty_scatter_kernel, dim3((unsigned)num_cus), dim3(256), 0, st, a, d);
     #if defined(MULUT_VARIANT_slablds64)
