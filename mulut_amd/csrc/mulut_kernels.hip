@@ -2795,7 +2795,11 @@ __device__ __forceinline__ void slab_row_addrs(const SlabPair &sp, uint32_t (&ad
 }
 template <int J>
 __device__ __forceinline__ uint4 slab_row(const uint32_t (&ad)[4]) {
+#if defined(MULUT_ABLATE) && MULUT_ABLATE == 51   /* timing-only: every lane of a wave reads row J's address of lane 0 (no bank conflicts) */
+    return lds_u128((uint32_t)__builtin_amdgcn_readfirstlane((int)ad[J < 4 ? J : 0]) + (uint32_t)(J < 4 ? 0 : kSlabAll * 16) + ((threadIdx.x & 15u) << 4));
+#else
     return lds_u128(ad[J < 4 ? J : 0] + (uint32_t)(J < 4 ? 0 : kSlabAll * 16));
+#endif
 }
 
 // Both passes of a rotation pair (R in the low halves of sp, R + 2 in the high halves) from the slab pair at LDS address 0.
@@ -2859,6 +2863,10 @@ __device__ __forceinline__ void slab_load_window_t(const StageArgs &a, uint32_t 
         if constexpr (kind != 0) {
             const int dyc = dy < 0 ? -imin(-dy, top) : imin(dy, bot);       // edge replication at the true image borders
             const uint8_t *p = p0 + dyc * a.in.sY;
+#if defined(MULUT_ABLATE) && MULUT_ABLATE == 52   /* timing-only: no window loads */
+            w.lo[r] = (uint32_t)(uintptr_t)p * 0x9E3779B1u;
+            w.hi[r] = w.lo[r] >> 7;
+#else
             if constexpr (kind == 1) {
                 uint32_t v;
                 __builtin_memcpy(&v, p + 1, 4);
@@ -2869,6 +2877,7 @@ __device__ __forceinline__ void slab_load_window_t(const StageArgs &a, uint32_t 
                 w.lo[r] = v.x;
                 w.hi[r] = v.y;
             }
+#endif
         }
     });
 }
@@ -2987,7 +2996,11 @@ __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, Detail
             const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;     // scalar
             const uint8_t *pair = d.slab[m] + (size_t)h * kSlabPairBytes;
             SLAB_CLK(3);                   // item set-up / epilogue / stores
+#if defined(MULUT_ABLATE) && MULUT_ABLATE == 54   /* timing-only: the slab pair is copied once per workgroup */
+            slab_mode(a, pat, cnt, pair, resident != nullptr, smem, desc, acc SLAB_CLK_PASS);
+#else
             slab_mode(a, pat, cnt, pair, pair == resident, smem, desc, acc SLAB_CLK_PASS);
+#endif
             resident = pair;
         }
         snake = !snake;
@@ -2996,7 +3009,11 @@ __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, Detail
             RotAcc<4> r;
             acc[s].to_fields(r);
             uint32_t o[4];
+#if defined(MULUT_ABLATE) && MULUT_ABLATE == 53   /* timing-only: no divide / round / clip */
+            o[0] = r.lo02[0] ^ r.lo13[0]; o[1] = r.lo02[1] ^ r.hi13[1]; o[2] = r.hi02[2] ^ r.lo13[2]; o[3] = r.hi02[3] ^ r.hi13[3];
+#else
             tube_finish_rows(a, r, o);
+#endif
             const uint32_t i = (uint32_t)s * kSlabNT + threadIdx.x;
             if (i < cnt) d.blocks[(desc[s] & 0x0FFFFFFFu) + 2u] = make_uint4(o[0], o[1], o[2], o[3]);      // indexed by the sample's byte offset in the stage input
         }
