@@ -25,7 +25,11 @@ def rgb2ycbcr(img, max_val=255):
     """common/utils.py:42-60 (BT.601 studio swing)."""
     off = _O / 255.0 if max_val == 1 else _O
     flat = np.reshape(img, (-1, img.shape[2])).astype(np.float64)
-    return (flat @ _T.T + off).reshape(img.shape)
+    # three scaled columns added up, NOT `flat @ _T.T`: the CLI scores images on several threads at once, and concurrent
+    # dgemm calls of the bundled OpenBLAS (0.3.29, threaded) on these tall 3-column operands were seen to return wrong rows
+    # now and then (tools/stress_cli.py: 19 of 300 Set5 runs printed a PSNR off by 0.03-0.6 dB with bit-exact PNGs)
+    out = flat[:, 0:1] * _T[:, 0] + flat[:, 1:2] * _T[:, 1] + flat[:, 2:3] * _T[:, 2] + off
+    return out.reshape(img.shape)
 
 
 def psnr(y_true, y_pred, shave_border=4):

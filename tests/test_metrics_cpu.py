@@ -42,3 +42,18 @@ def test_set5_scores_match_reference(fx):
         vals.append((p, s))
     m = np.mean(vals, axis=0)
     assert "{:.2f} {:.4f}".format(*m) == "30.61 0.8656"       # sr/4_test_lut.py:260 summary line
+
+
+def test_scores_do_not_depend_on_concurrent_callers(fx):
+    """The CLI scores finished images on several threads at once (eltr.run): the same five Set5 pairs scored by four threads,
+    40 rounds, must give the single-threaded numbers every time (a BLAS matmul inside rgb2ycbcr did not)."""
+    from concurrent.futures import ThreadPoolExecutor
+    pairs = []
+    for k in sorted(k for k in fx.files if k.startswith("set5/")):
+        stem = k.split("/")[1]
+        out = np.array(Image.open(os.path.join(GOLDEN, "Set5", "ref_out", stem + "_LUT_ft_4bit.png")))
+        pairs.append((modcrop(np.array(Image.open(os.path.join(GOLDEN, "Set5", "HR", stem + ".png"))), 4), out))
+    want = [_score(gt, out, 4) for gt, out in pairs]
+    with ThreadPoolExecutor(4) as ex:
+        for _ in range(40):
+            assert list(ex.map(lambda p: _score(p[0], p[1], 4), pairs)) == want
