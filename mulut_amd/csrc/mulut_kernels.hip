@@ -2259,10 +2259,10 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
             for (int k = 0; k < 4; ++k) o0[k] = o1[k] = o2[k] = 0;
             // per channel: != 0 when some pass of the sample may have left the tube (FLAGGED: bit c of site_flag_kernel's byte)
             const uint32_t sflags = FLAGGED ? (uint32_t)a.site_flags[((size_t)n * a.H + y) * a.W + x] : 0u;
-            const uint32_t pixel_id = (uint32_t)((n * a.H + y) * a.W + x);
+            uint32_t dmask = FLAGGED ? sflags & 7u : 0u;      // bit c: channel c is dirty
 #pragma clang loop unroll(disable)
             for (int c = 0; c < a.C; ++c, win += 2 * PH * PW) {
-                uint32_t dirty = FLAGGED ? ((sflags >> c) & 1u) : 0u;
+                uint32_t dirty = 0u;
                 const uint32_t ca = *(const uint16_t *)(smem + win + 2 * (2 * PW + 2));
                 const uint32_t k0 = tube_anchor_key(ca), ha16 = tube_anchor_h16(ca), ha27 = pk_mad(ha16, pk_dup(kTubeSA), 0u);
                 RotAcc<4> acc;
@@ -2282,17 +2282,23 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
                     uint32_t o[4];
                     finish_channel<4, OUT>(a, acc, n, c, y, x, o);
                 }
-                // dirty samples (pixel, channel) go on the fix-up list: one atomic per wave (rare), compacted by lane rank
-                const unsigned long long dm = __ballot(dirty != 0u);
-                if (dm != 0ull) {
+                if constexpr (!FLAGGED) dmask |= (dirty != 0u ? 1u : 0u) << c;
+            }
+            if constexpr (OUT == kOutPackedRGBU4) store_rgb<4>(a, n, y, x, o0, o1, o2);
+            // dirty samples (pixel, channel) go on the fix-up list: one atomic per wave and channel (rare), compacted by lane rank
+            if (__ballot(dmask != 0u) != 0ull) {
+                const uint32_t pixel_id = (uint32_t)((n * a.H + y) * a.W + x);
+                for (int c = 0; c < a.C; ++c) {
+                    const bool d = ((dmask >> c) & 1u) != 0u;
+                    const unsigned long long dm = __ballot(d);
+                    if (dm == 0ull) continue;
                     const int lane = (int)(threadIdx.x & 63);
                     uint32_t at = 0;
                     if (lane == __ffsll((long long)dm) - 1) at = atomicAdd(a.fix_count, (uint32_t)__popcll(dm));
                     at = (uint32_t)__shfl((int)at, __ffsll((long long)dm) - 1);
-                    if (dirty != 0u) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = pixel_id | ((uint32_t)c << 30);
+                    if (d) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = pixel_id | ((uint32_t)c << 30);
                 }
             }
-            if constexpr (OUT == kOutPackedRGBU4) store_rgb<4>(a, n, y, x, o0, o1, o2);
         }
         if (nxt < last) stash(nxt, (it + 1) & 1, pix);
         __syncthreads();     // next tile published; everyone is done reading the current one
