@@ -57,7 +57,7 @@ struct StageArgs {
     // 1-byte-row tube kernel: tile_list[tile] = 1 for the tiles it leaves to the full-table kernel (stage_u1w_kernel in
     // list mode); zeroed by the host side before the stage
     uint32_t *tile_list;
-    uint32_t *tile_count;     // unused
+    uint32_t *tile_count;     // number of tiles marked in tile_list (the tube kernel counts, the list kernel sizes its work units by it)
 };
 
 struct PassArgs {

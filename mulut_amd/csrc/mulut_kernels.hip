@@ -364,17 +364,22 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
     constexpr bool listed = LIST;
     const int nt_all = a.N * a.tiles_x * a.tiles_y;
     const int G = (int)gridDim.x;
+    // few marked tiles (fewer than half the workgroups): the unit of work is one CHANNEL of a tile, so that the launch does
+    // not last as long as one whole tile (100 us) while most CUs have nothing to do
+    const int nsub = (listed && a.tile_count && *a.tile_count * 2u < (uint32_t)G) ? a.C : 1;       // workgroup-uniform
+    const int nu_all = nt_all * nsub;
     const bool by_xcd = (G & 7) == 0;
-    const int per = (nt_all + 7) >> 3;
+    const int per = (nu_all + 7) >> 3;
     int t_cur = !listed ? 0 : by_xcd ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int t_last = !listed ? 1 : by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, nt_all) : nt_all;
+    const int t_last = !listed ? 1 : by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, nu_all) : nu_all;
     const int t_step = !listed ? 1 : by_xcd ? (G >> 3) : G;
     for (;; t_cur += t_step) {
-    int n, y0, x0;
+    int n, y0, x0, c_lo = 0, c_n = a.C;
     if (listed) {
-        while (t_cur < t_last && a.tile_list[t_cur] == 0u) t_cur += t_step;       // workgroup-uniform
+        while (t_cur < t_last && a.tile_list[t_cur / nsub] == 0u) t_cur += t_step;       // workgroup-uniform
         if (t_cur >= t_last) break;
-        decode_tile(a, t_cur, n, y0, x0, TW, TH);
+        decode_tile(a, t_cur / nsub, n, y0, x0, TW, TH);
+        if (nsub > 1) { c_lo = t_cur % nsub; c_n = 1; }
     } else {
         decode_tile(a, xcd_remap(blockIdx.x, gridDim.x), n, y0, x0, TW, TH);
     }
@@ -409,20 +414,21 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
         __syncthreads();  // table and (m == 0) tile in place
         // pattern of this mode from its first key offset: s (0,1), d (0,2), y (1,1) -- scalar
         const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
-        if (pat == 0) u1w_mode<0, PW, PH>(s_lut, s_img, ty, x4, a.C, acc);
-        else if (pat == 1) u1w_mode<1, PW, PH>(s_lut, s_img, ty, x4, a.C, acc);
-        else u1w_mode<2, PW, PH>(s_lut, s_img, ty, x4, a.C, acc);
+        const uint8_t *img_c = s_img + c_lo * (PH * PW);
+        if (pat == 0) u1w_mode<0, PW, PH>(s_lut, img_c, ty, x4, c_n, acc);
+        else if (pat == 1) u1w_mode<1, PW, PH>(s_lut, img_c, ty, x4, c_n, acc);
+        else u1w_mode<2, PW, PH>(s_lut, img_c, ty, x4, c_n, acc);
     }
     const int y = y0 + ty;
     if (y < a.oy1) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            if (c < a.C) {
+            if (c < c_n) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int x = x0 + x4 + i;
                     if (x < a.W)
-                        *const_cast<uint8_t *>(view_addr(a.out, n, c, y, x)) = (uint8_t)rhe_clip_u8(acc[c * 4 + i] + a.bias_num, a.div);
+                        *const_cast<uint8_t *>(view_addr(a.out, n, c_lo + c, y, x)) = (uint8_t)rhe_clip_u8(acc[c * 4 + i] + a.bias_num, a.div);
                 }
             }
     }
@@ -773,7 +779,12 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
             if ((threadIdx.x & 63) == 0 && seen) { atomicAdd(&s_cnt[0], far); atomicAdd(&s_cnt[1], seen); }
             __syncthreads();
             if (s_cnt[0] * 1024u > detail_per_1024 * s_cnt[1]) {       // workgroup-uniform
-                if (threadIdx.x == 0) a.tile_list[tile] = 1u;      // verdict: left to the full-table kernel
+                if (threadIdx.x == 0) {      // verdict: left to the full-table kernel
+                    a.tile_list[tile] = 1u;
+                    // counted only while few: the list kernel asks "fewer than half the workgroups?", and on detailed content tens of
+                    // thousands of atomics on one address would be a cost of their own
+                    if (a.tile_count && __hip_atomic_load(a.tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1024u) atomicAdd(a.tile_count, 1u);
+                }
                 continue;
             }
         }
