@@ -2326,6 +2326,10 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
 // launch is unconditional (hipGraph-capturable) and costs a few microseconds when the list is empty.
 template <int OUT>
 __global__ void __launch_bounds__(256) stage_up_fix_kernel(StageArgs a) {
+    // a thread's 5x5 window as five 8-byte rows (from column x - 2) in its own LDS slot: the 36 neighbour reads of a sample are
+    // LDS byte reads then, not global ones (the kernel is bound by the texture path).  Border columns (and inputs that are
+    // not planar) read the image directly, with edge replication.
+    __shared__ uint2 s_win[5][256];
     const uint32_t count = *a.fix_count;
     const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
@@ -2334,7 +2338,17 @@ __global__ void __launch_bounds__(256) stage_up_fix_kernel(StageArgs a) {
         const int x = (int)(id % (uint32_t)a.W), y = (int)((id / (uint32_t)a.W) % (uint32_t)a.H), n = (int)(id / ((uint32_t)a.W * (uint32_t)a.H));
         for (int c = 0; c < a.C; ++c) {
             if (only != 3u && (uint32_t)c != only) continue;
+            const bool inner = a.in.sX == 1 && x >= kSlabXLo && x < a.W - slab_x_hi(a);      // 8 bytes from x - 2 stay inside the row / the padding
+            if (inner) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    uint2 v;
+                    __builtin_memcpy(&v, view_addr(a.in, n, c, imin(imax(y + q - 2, ylo), yhi), x - 2), 8);
+                    s_win[q][threadIdx.x] = v;
+                }
+            }
             auto px = [&](int dy, int dx) {
+                if (inner) return (int)((const uint8_t *)&s_win[dy + 2][threadIdx.x])[dx + 2];
                 const int gy = imin(imax(y + dy, ylo), yhi), gx = imin(imax(x + dx, 0), a.W - 1);
                 return (int)*view_addr(a.in, n, c, gy, gx);
             };
