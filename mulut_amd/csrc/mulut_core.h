@@ -535,6 +535,53 @@ MULUT_HD uint32_t slab_rev_odd_bytes(uint32_t x) { return ((x >> 16) & 0xFFu) | 
 #endif
 MULUT_HD uint32_t slab_even_sums(uint32_t F, uint32_t H) { return pk_mad(H, pk_dup(0xFF00u), F); }
 
+// ---- full-table pairs for 1-byte rows (first-stage kernel on detailed tiles) ------------------------------
+// Rotations r / r + 2 of one site in packed halves against the WHOLE table (row index A 4913 + B 289 + C 17 + D).  The
+// strides of b, c, d fit the 12 bits under f in a sort key; the anchor's 4913 does not, so the anchor's key carries a marker
+// (bit 11, above any sum of the other strides: 289 + 17 + 1 = 307) and a row's offset is
+//     base + (cum & 0x7FF) + (cum >> 11 & 1) * 4913        cum = running sum of the sorted keys' low 12 bits.
+//   in : k0 = anchor key pair (f << 12 | 0x800 per half), pb/pc/pd = neighbour BYTES of rotation r (low half) and r + 2 (high)
+//   out: base = B 289 + C 17 + D per half (the caller adds A 4913), cum[0..2] = running sums after path steps 1..3 per half,
+//        w[5] = weights per half; row 4 = base + kAllStrides
+struct FullPair1 {
+    uint32_t base;
+    uint32_t cum[3];
+    uint32_t w[5];
+};
+constexpr uint32_t kFullMark = 0x800u;
+MULUT_HD uint32_t full1_anchor_key(uint32_t va) { return pk_dup(((va & 15u) << 12) | kFullMark); }
+MULUT_HD void simplex4_full_pair1(uint32_t k0, uint32_t pb, uint32_t pc, uint32_t pd, FullPair1 &o) {
+    uint32_t k1 = pk_mad(pb, pk_dup(4096u), pk_dup(kStrideB));
+    uint32_t k2 = pk_mad(pc, pk_dup(4096u), pk_dup(kStrideC));
+    uint32_t k3 = pk_mad(pd, pk_dup(4096u), pk_dup(kStrideD));
+    const uint32_t hb = pk_shr4(pb), hc = pk_shr4(pc), hd = pk_shr4(pd);
+    pk_cmpx_desc(k0, k1);
+    pk_cmpx_desc(k2, k3);
+    pk_cmpx_desc(k0, k2);
+    pk_cmpx_desc(k1, k3);
+    pk_cmpx_desc(k1, k2);
+    const uint32_t f1 = pk_shr12(k0), f2 = pk_shr12(k1), f3 = pk_shr12(k2), f4 = pk_shr12(k3);
+    o.base = pk_mad(hb, pk_dup(kStrideB), pk_mad(hc, pk_dup(kStrideC), hd));      // <= 15 * 307: no carry between halves
+    o.cum[0] = k0 & 0x0FFF0FFFu;
+    o.cum[1] = o.cum[0] + (k1 & 0x0FFF0FFFu);                                      // <= 0x800 + 307 per half
+    o.cum[2] = o.cum[1] + (k2 & 0x0FFF0FFFu);
+    o.w[0] = pk_dup(kQ) - f1;
+    o.w[1] = f1 - f2;
+    o.w[2] = f2 - f3;
+    o.w[3] = f3 - f4;
+    o.w[4] = f4;
+}
+// row offsets (from table + A 4913) of one pass
+MULUT_HD void full_pair1_rows(const FullPair1 &p, int half, uint32_t (&r)[5]) {
+    const uint32_t b = half ? (p.base >> 16) : (p.base & 0xFFFFu);
+    r[0] = b;
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t c = half ? (p.cum[j] >> 16) : (p.cum[j] & 0xFFFFu);
+        r[j + 1] = b + (c & 0x7FFu) + ((c >> 11) & 1u) * (uint32_t)kStrideA;
+    }
+    r[4] = b + (uint32_t)kAllStrides;
+}
+
 // ---- merged rotation pairs ----------------------------------------------------------------------------
 // Rotation r+2 maps row element e to the block position that rotation r gives element 15-e
 // (row_elem(r+2,sy,sx,4) == 15 - row_elem(r,sy,sx,4)), so the rows of rotation r+2 can be added

@@ -351,6 +351,96 @@ __device__ __forceinline__ void u1w_mode(const int8_t *s_lut, const uint8_t *s_i
     }
 }
 
+// dst = a + (16-bit half SEL of b): one SDWA add extracts and adds
+template <int SEL>
+__device__ __forceinline__ uint32_t add_word(uint32_t a, uint32_t b) {
+    uint32_t r;
+    if constexpr (SEL == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// The same mode with rotations r / r + 2 of a pixel in packed 16-bit halves (simplex4_full_pair1): 33 VALU instructions per
+// pass instead of 49.  A neighbour pair is one v_perm_b32 of two window registers; the row offsets are rebuilt per pass from
+// the packed running sums (one SDWA add, one bit-field extract and one multiply-add per row: the anchor's 13-bit stride rides
+// as a marker bit); the two passes' values of a row are packed by a v_perm_b32 and accumulated by one v_dot2_i32_i16.
+template <int Q1, int J1, int Q2, int J2>
+__device__ __forceinline__ uint32_t win_byte_pair(const uint32_t (&win)[5][2]) {      // byte (Q1, J1) | byte (Q2, J2) << 16
+    constexpr uint32_t sel = 0x0C000C00u | ((uint32_t)(4 + (J2 & 3)) << 16) | (uint32_t)(J1 & 3);
+    return __builtin_amdgcn_perm(win[Q2][J2 >> 2], win[Q1][J1 >> 2], sel);
+}
+template <int HALF>
+__device__ __forceinline__ uint32_t bfe_mark(uint32_t cum) {      // the marker bit of half HALF
+    return __builtin_amdgcn_ubfe(cum, 11 + 16 * HALF, 1);
+}
+template <int PAT, int R>
+__device__ __forceinline__ int u1p_pair(const int8_t *s_lut, const uint32_t (&win)[5][2], uint32_t k0, uint32_t ta, int sum) {
+    constexpr int yb = rot_dy(R, kPatDi[PAT][0], kPatDj[PAT][0]), xb = rot_dx(R, kPatDi[PAT][0], kPatDj[PAT][0]);
+    constexpr int yc = rot_dy(R, kPatDi[PAT][1], kPatDj[PAT][1]), xc = rot_dx(R, kPatDi[PAT][1], kPatDj[PAT][1]);
+    constexpr int yd = rot_dy(R, kPatDi[PAT][2], kPatDj[PAT][2]), xd = rot_dx(R, kPatDi[PAT][2], kPatDj[PAT][2]);
+    FullPair1 fp;
+    simplex4_full_pair1(k0, win_byte_pair<2 + yb, 2 + xb, 2 - yb, 2 - xb>(win), win_byte_pair<2 + yc, 2 + xc, 2 - yc, 2 - xc>(win),
+                        win_byte_pair<2 + yd, 2 + xd, 2 - yd, 2 - xd>(win), fp);
+    uint32_t ra[4], rb[4];
+    ra[0] = add_word<0>(ta, fp.base);
+    rb[0] = add_word<1>(ta, fp.base);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // base + running sum (its marker counts 2048 here) + marker * (4913 - 2048)
+        ra[j + 1] = bfe_mark<0>(fp.cum[j]) * (uint32_t)(kStrideA - (int)kFullMark) + add_word<0>(ra[0], fp.cum[j]);
+        rb[j + 1] = bfe_mark<1>(fp.cum[j]) * (uint32_t)(kStrideA - (int)kFullMark) + add_word<1>(rb[0], fp.cum[j]);
+    }
+    int va[5], vb[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        va[j] = (int)s_lut[ra[j < 4 ? j : 0] + (uint32_t)(j < 4 ? 0 : kAllStrides)];
+        vb[j] = (int)s_lut[rb[j < 4 ? j : 0] + (uint32_t)(j < 4 ? 0 : kAllStrides)];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const uint32_t t = __builtin_amdgcn_perm((uint32_t)vb[j], (uint32_t)va[j], 0x05040100u);      // value of pass A | value of pass B
+        sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, fp.w[j]), sum, false);
+    }
+    return sum;
+}
+template <int PAT, int PW, int PH>
+__device__ __forceinline__ void u1p_mode(const int8_t *s_lut, const uint8_t *s_img, int ty, int x4, int C, int (&acc)[12]) {
+    int c = 0;
+#pragma clang loop unroll(disable)
+    for (; c < C; ++c) {
+        const uint32_t *row = (const uint32_t *)(s_img + c * (PH * PW) + ty * PW + x4);
+        uint32_t win[5][2];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            win[q][0] = row[q * (PW / 4)];
+            win[q][1] = row[q * (PW / 4) + 1];
+        }
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t va = (win[2][0] >> 16) & 0xFFu;
+            uint32_t k0 = full1_anchor_key(va);
+            const uint32_t ta = (va >> 4) * (uint32_t)kStrideA;
+            int sum = u1p_pair<PAT, 0>(s_lut, win, k0, ta, acc[0]);
+            asm volatile("" : "+v"(sum), "+v"(k0));      // one pair at a time (register budget)
+            sum = u1p_pair<PAT, 1>(s_lut, win, k0, ta, sum);
+            acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = acc[3]; acc[3] = sum;       // next pixel's accumulator to slot 0
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {                                            // window one pixel to the left
+                win[q][0] = __builtin_amdgcn_alignbit(win[q][1], win[q][0], 8);
+                win[q][1] >>= 8;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int t = acc[k]; acc[k] = acc[4 + k]; acc[4 + k] = acc[8 + k]; acc[8 + k] = t; }
+    }
+#pragma clang loop unroll(disable)
+    for (; c < 3; ++c) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int t = acc[k]; acc[k] = acc[4 + k]; acc[4 + k] = acc[8 + k]; acc[8 + k] = t; }
+    }
+}
+
 template <int TW, int TH, int NT, bool LIST>
 __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
     constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
@@ -415,9 +505,15 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
         // pattern of this mode from its first key offset: s (0,1), d (0,2), y (1,1) -- scalar
         const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
         const uint8_t *img_c = s_img + c_lo * (PH * PW);
+#if defined(MULUT_VARIANT_u1wold)
         if (pat == 0) u1w_mode<0, PW, PH>(s_lut, img_c, ty, x4, c_n, acc);
         else if (pat == 1) u1w_mode<1, PW, PH>(s_lut, img_c, ty, x4, c_n, acc);
         else u1w_mode<2, PW, PH>(s_lut, img_c, ty, x4, c_n, acc);
+#else
+        if (pat == 0) u1p_mode<0, PW, PH>(s_lut, img_c, ty, x4, c_n, acc);
+        else if (pat == 1) u1p_mode<1, PW, PH>(s_lut, img_c, ty, x4, c_n, acc);
+        else u1p_mode<2, PW, PH>(s_lut, img_c, ty, x4, c_n, acc);
+#endif
     }
     const int y = y0 + ty;
     if (y < a.oy1) {
@@ -2077,14 +2173,6 @@ __device__ __forceinline__ void tube_mac_row(RotAcc<4> &acc, const uint4 &lo, co
     acc.template mac_x<R, HALF>(rlo, rhi, wpk);
 }
 
-// dst = a + (16-bit half SEL of b): one SDWA add extracts and adds
-template <int SEL>
-__device__ __forceinline__ uint32_t add_word(uint32_t a, uint32_t b) {
-    uint32_t r;
-    if constexpr (SEL == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
-    else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 
 // the five rows of one pass: all ten reads issued, then accumulated in order.  The byte offsets are built unpacked (one
 // SDWA add per row extracts the pass's half of the packed stride and adds it); row 4 (vertex 1111) sits a fixed 65

@@ -167,6 +167,43 @@ extern "C" long emul_check_band_pair(int step) {
     return bad;
 }
 
+// Full-table pairs for 1-byte rows: rows and weights of the packed pair math == the scalar simplex, for every key combination
+// (sampled in three of the keys).
+extern "C" long emul_check_full_pair1(int step) {
+    long bad = 0;
+    for (int va = 0; va < 256; va += step)
+        for (int vb = 0; vb < 256; vb += step)
+            for (int vc = 0; vc < 256; vc += step)
+                for (int vd = 0; vd < 256; vd += 1) {
+                    const int vb2 = (vb * 7 + 3) & 255, vc2 = (vc * 5 + 11) & 255, vd2 = 255 - vd;
+                    FullPair1 fp;
+                    simplex4_full_pair1(full1_anchor_key((uint32_t)va), (uint32_t)vb | ((uint32_t)vb2 << 16), (uint32_t)vc | ((uint32_t)vc2 << 16),
+                                        (uint32_t)vd | ((uint32_t)vd2 << 16), fp);
+                    for (int half = 0; half < 2; ++half) {
+                        const int b = half ? vb2 : vb, c = half ? vc2 : vc, d = half ? vd2 : vd;
+                        int idx[5], w[5];
+                        simplex4(va, b, c, d, idx, w);
+                        uint32_t r[5];
+                        full_pair1_rows(fp, half, r);
+                        int wp[5];
+                        for (int j = 0; j < 5; ++j) {
+                            wp[j] = (int)(half ? (fp.w[j] >> 16) : (fp.w[j] & 0xFFFFu));
+                            r[j] += (uint32_t)((va >> 4) * kStrideA);
+                            if (r[j] >= (uint32_t)kRows) ++bad;
+                        }
+                        for (int j = 0; j < 5; ++j) {
+                            int ws = 0, wq = 0;
+                            for (int i = 0; i < 5; ++i) {
+                                if (idx[i] == idx[j]) ws += w[i];
+                                if ((int)r[i] == idx[j]) wq += wp[i];
+                            }
+                            if (ws != wq) ++bad;
+                        }
+                    }
+                }
+    return bad;
+}
+
 // Slab pairs (mulut_core.h): for every key combination the packed pair math must give the rows of the scalar simplex
 // as (anchor slab flag, (b, c, d) offset) with the same weight per row, and the raw-byte accumulation over a whole
 // sample (3 modes x 4 rotations, rotations r + 2 reversed into the pair's accumulator) must reproduce the field sums.

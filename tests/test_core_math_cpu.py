@@ -90,6 +90,12 @@ def test_band_pair_index_math(emul):
     assert emul.emul_check_band_pair(5) == 0
 
 
+def test_full_table_pair_math_for_one_byte_rows(emul):
+    """mulut_core.h full-table pairs (first stage, detailed tiles): rows / weights == the scalar simplex"""
+    emul.emul_check_full_pair1.restype = ctypes.c_long
+    assert emul.emul_check_full_pair1(5) == 0
+
+
 def test_slab_pair_index_math_and_raw_byte_accumulation(emul):
     """mulut_core.h slab pairs: rows / weights of the packed pair math == the scalar simplex for every key combination
     (sampled), and F / H raw-byte accumulation == the 16-bit field sums up to the 4-mode bound"""
