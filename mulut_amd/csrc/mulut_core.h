@@ -201,6 +201,7 @@ MULUT_HD uint32_t pk_max(uint32_t a, uint32_t b) { return MULUT_UNPK(__builtin_e
 MULUT_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return MULUT_UNPK(MULUT_PK(a) * MULUT_PK(b) + MULUT_PK(c)); }
 MULUT_HD uint32_t pk_shr12(uint32_t a) { return MULUT_UNPK(MULUT_PK(a) >> (unsigned short)12); }
 MULUT_HD uint32_t pk_shr4(uint32_t a) { return MULUT_UNPK(MULUT_PK(a) >> (unsigned short)4); }
+MULUT_HD uint32_t pk_shr11(uint32_t a) { return MULUT_UNPK(MULUT_PK(a) >> (unsigned short)11); }
 MULUT_HD uint32_t pk_sub_sat(uint32_t a, uint32_t b) { return MULUT_UNPK(__builtin_elementwise_sub_sat(MULUT_PK(a), MULUT_PK(b))); }
 #else
 MULUT_HD uint32_t pk_add(uint32_t a, uint32_t b) { return ((a + b) & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16); }
@@ -220,6 +221,7 @@ MULUT_HD uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
 }
 MULUT_HD uint32_t pk_shr12(uint32_t a) { return ((a & 0xFFFFu) >> 12) | (((a >> 16) >> 12) << 16); }
 MULUT_HD uint32_t pk_shr4(uint32_t a) { return ((a & 0xFFFFu) >> 4) | (((a >> 16) >> 4) << 16); }
+MULUT_HD uint32_t pk_shr11(uint32_t a) { return ((a & 0xFFFFu) >> 11) | (((a >> 16) >> 11) << 16); }
 MULUT_HD uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
     const uint32_t l = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) - (b & 0xFFFFu) : 0u;
     const uint32_t h = (a >> 16) > (b >> 16) ? (a >> 16) - (b >> 16) : 0u;
@@ -541,8 +543,8 @@ MULUT_HD uint32_t slab_even_sums(uint32_t F, uint32_t H) { return pk_mad(H, pk_d
 // (bit 11, above any sum of the other strides: 289 + 17 + 1 = 307) and a row's offset is
 //     base + (cum & 0x7FF) + (cum >> 11 & 1) * 4913        cum = running sum of the sorted keys' low 12 bits.
 //   in : k0 = anchor key pair (f << 12 | 0x800 per half), pb/pc/pd = neighbour BYTES of rotation r (low half) and r + 2 (high)
-//   out: base = B 289 + C 17 + D per half (the caller adds A 4913), cum[0..2] = running sums after path steps 1..3 per half,
-//        w[5] = weights per half; row 4 = base + kAllStrides
+//   out: base = B 289 + C 17 + D per half (the caller adds A 4913), cum[0..2] = offsets of rows 1..3 from row 0 per half
+//        (the marker already turned into the anchor's stride), w[5] = weights per half; row 4 = base + kAllStrides
 struct FullPair1 {
     uint32_t base;
     uint32_t cum[3];
@@ -562,9 +564,13 @@ MULUT_HD void simplex4_full_pair1(uint32_t k0, uint32_t pb, uint32_t pc, uint32_
     pk_cmpx_desc(k1, k2);
     const uint32_t f1 = pk_shr12(k0), f2 = pk_shr12(k1), f3 = pk_shr12(k2), f4 = pk_shr12(k3);
     o.base = pk_mad(hb, pk_dup(kStrideB), pk_mad(hc, pk_dup(kStrideC), hd));      // <= 15 * 307: no carry between halves
-    o.cum[0] = k0 & 0x0FFF0FFFu;
-    o.cum[1] = o.cum[0] + (k1 & 0x0FFF0FFFu);                                      // <= 0x800 + 307 per half
-    o.cum[2] = o.cum[1] + (k2 & 0x0FFF0FFFu);
+    const uint32_t c0 = k0 & 0x0FFF0FFFu;
+    const uint32_t c1 = c0 + (k1 & 0x0FFF0FFFu);                                   // <= 0x800 + 307 per half
+    const uint32_t c2 = c1 + (k2 & 0x0FFF0FFFu);
+    // marker (2048) -> the anchor's stride: + (cum >> 11) * (4913 - 2048), both halves at once
+    o.cum[0] = pk_mad(pk_shr11(c0), pk_dup((uint32_t)kStrideA - kFullMark), c0);
+    o.cum[1] = pk_mad(pk_shr11(c1), pk_dup((uint32_t)kStrideA - kFullMark), c1);
+    o.cum[2] = pk_mad(pk_shr11(c2), pk_dup((uint32_t)kStrideA - kFullMark), c2);
     o.w[0] = pk_dup(kQ) - f1;
     o.w[1] = f1 - f2;
     o.w[2] = f2 - f3;
@@ -576,8 +582,7 @@ MULUT_HD void full_pair1_rows(const FullPair1 &p, int half, uint32_t (&r)[5]) {
     const uint32_t b = half ? (p.base >> 16) : (p.base & 0xFFFFu);
     r[0] = b;
     for (int j = 0; j < 3; ++j) {
-        const uint32_t c = half ? (p.cum[j] >> 16) : (p.cum[j] & 0xFFFFu);
-        r[j + 1] = b + (c & 0x7FFu) + ((c >> 11) & 1u) * (uint32_t)kStrideA;
+        r[j + 1] = b + (half ? (p.cum[j] >> 16) : (p.cum[j] & 0xFFFFu));
     }
     r[4] = b + (uint32_t)kAllStrides;
 }

@@ -362,33 +362,28 @@ __device__ __forceinline__ uint32_t add_word(uint32_t a, uint32_t b) {
 
 // The same mode with rotations r / r + 2 of a pixel in packed 16-bit halves (simplex4_full_pair1): 33 VALU instructions per
 // pass instead of 49.  A neighbour pair is one v_perm_b32 of two window registers; the row offsets are rebuilt per pass from
-// the packed running sums (one SDWA add, one bit-field extract and one multiply-add per row: the anchor's 13-bit stride rides
-// as a marker bit); the two passes' values of a row are packed by a v_perm_b32 and accumulated by one v_dot2_i32_i16.
+// the packed running sums (one SDWA add per row; the anchor's 13-bit stride rides as a marker bit that the pair math turns
+// into the stride for both halves at once); the two passes' values of a row are packed by a v_perm_b32 and accumulated by one v_dot2_i32_i16.
 template <int Q1, int J1, int Q2, int J2>
 __device__ __forceinline__ uint32_t win_byte_pair(const uint32_t (&win)[5][2]) {      // byte (Q1, J1) | byte (Q2, J2) << 16
     constexpr uint32_t sel = 0x0C000C00u | ((uint32_t)(4 + (J2 & 3)) << 16) | (uint32_t)(J1 & 3);
     return __builtin_amdgcn_perm(win[Q2][J2 >> 2], win[Q1][J1 >> 2], sel);
 }
-template <int HALF>
-__device__ __forceinline__ uint32_t bfe_mark(uint32_t cum) {      // the marker bit of half HALF
-    return __builtin_amdgcn_ubfe(cum, 11 + 16 * HALF, 1);
-}
-template <int PAT, int R>
+template <int PAT, int R, int I>
 __device__ __forceinline__ int u1p_pair(const int8_t *s_lut, const uint32_t (&win)[5][2], uint32_t k0, uint32_t ta, int sum) {
     constexpr int yb = rot_dy(R, kPatDi[PAT][0], kPatDj[PAT][0]), xb = rot_dx(R, kPatDi[PAT][0], kPatDj[PAT][0]);
     constexpr int yc = rot_dy(R, kPatDi[PAT][1], kPatDj[PAT][1]), xc = rot_dx(R, kPatDi[PAT][1], kPatDj[PAT][1]);
     constexpr int yd = rot_dy(R, kPatDi[PAT][2], kPatDj[PAT][2]), xd = rot_dx(R, kPatDi[PAT][2], kPatDj[PAT][2]);
-    FullPair1 fp;
-    simplex4_full_pair1(k0, win_byte_pair<2 + yb, 2 + xb, 2 - yb, 2 - xb>(win), win_byte_pair<2 + yc, 2 + xc, 2 - yc, 2 - xc>(win),
-                        win_byte_pair<2 + yd, 2 + xd, 2 - yd, 2 - xd>(win), fp);
+    FullPair1 fp;      // pixel I of the thread's four: its window is columns I .. I + 4 of the 8 the registers hold
+    simplex4_full_pair1(k0, win_byte_pair<2 + yb, I + 2 + xb, 2 - yb, I + 2 - xb>(win), win_byte_pair<2 + yc, I + 2 + xc, 2 - yc, I + 2 - xc>(win),
+                        win_byte_pair<2 + yd, I + 2 + xd, 2 - yd, I + 2 - xd>(win), fp);
     uint32_t ra[4], rb[4];
     ra[0] = add_word<0>(ta, fp.base);
     rb[0] = add_word<1>(ta, fp.base);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        // base + running sum (its marker counts 2048 here) + marker * (4913 - 2048)
-        ra[j + 1] = bfe_mark<0>(fp.cum[j]) * (uint32_t)(kStrideA - (int)kFullMark) + add_word<0>(ra[0], fp.cum[j]);
-        rb[j + 1] = bfe_mark<1>(fp.cum[j]) * (uint32_t)(kStrideA - (int)kFullMark) + add_word<1>(rb[0], fp.cum[j]);
+        ra[j + 1] = add_word<0>(ra[0], fp.cum[j]);
+        rb[j + 1] = add_word<1>(rb[0], fp.cum[j]);
     }
     int va[5], vb[5];
 #pragma unroll
@@ -404,41 +399,31 @@ __device__ __forceinline__ int u1p_pair(const int8_t *s_lut, const uint32_t (&wi
     }
     return sum;
 }
+// acc[4 c + i]: pixel i of channel c.  The four pixels are unrolled with immediate window columns: no window shifting, no
+// accumulator rotation (the rolled pixel loop of u1w_mode spends 13 of its 49 instructions per pass on those).
 template <int PAT, int PW, int PH>
 __device__ __forceinline__ void u1p_mode(const int8_t *s_lut, const uint8_t *s_img, int ty, int x4, int C, int (&acc)[12]) {
-    int c = 0;
-#pragma clang loop unroll(disable)
-    for (; c < C; ++c) {
-        const uint32_t *row = (const uint32_t *)(s_img + c * (PH * PW) + ty * PW + x4);
-        uint32_t win[5][2];
+    static_for<0, 3>([&](auto CC) {
+        constexpr int c = CC;
+        if (c < C) {          // workgroup-uniform
+            const uint32_t *row = (const uint32_t *)(s_img + c * (PH * PW) + ty * PW + x4);
+            uint32_t win[5][2];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            win[q][0] = row[q * (PW / 4)];
-            win[q][1] = row[q * (PW / 4) + 1];
-        }
-#pragma clang loop unroll(disable)
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t va = (win[2][0] >> 16) & 0xFFu;
-            uint32_t k0 = full1_anchor_key(va);
-            const uint32_t ta = (va >> 4) * (uint32_t)kStrideA;
-            int sum = u1p_pair<PAT, 0>(s_lut, win, k0, ta, acc[0]);
-            asm volatile("" : "+v"(sum), "+v"(k0));      // one pair at a time (register budget)
-            sum = u1p_pair<PAT, 1>(s_lut, win, k0, ta, sum);
-            acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = acc[3]; acc[3] = sum;       // next pixel's accumulator to slot 0
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {                                            // window one pixel to the left
-                win[q][0] = __builtin_amdgcn_alignbit(win[q][1], win[q][0], 8);
-                win[q][1] >>= 8;
+            for (int q = 0; q < 5; ++q) {
+                win[q][0] = row[q * (PW / 4)];
+                win[q][1] = row[q * (PW / 4) + 1];
             }
+            static_for<0, 4>([&](auto II) {
+                constexpr int i = II;
+                const uint32_t va = (i + 2 < 4 ? (win[2][0] >> (8 * ((i + 2) & 3))) : (win[2][1] >> (8 * ((i + 2) & 3)))) & 0xFFu;
+                uint32_t k0 = full1_anchor_key(va);
+                const uint32_t ta = (va >> 4) * (uint32_t)kStrideA;
+                int sum = u1p_pair<PAT, 0, i>(s_lut, win, k0, ta, acc[4 * c + i]);
+                asm volatile("" : "+v"(sum), "+v"(k0));      // one pair at a time (register budget)
+                acc[4 * c + i] = u1p_pair<PAT, 1, i>(s_lut, win, k0, ta, sum);
+            });
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const int t = acc[k]; acc[k] = acc[4 + k]; acc[4 + k] = acc[8 + k]; acc[8 + k] = t; }
-    }
-#pragma clang loop unroll(disable)
-    for (; c < 3; ++c) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const int t = acc[k]; acc[k] = acc[4 + k]; acc[4 + k] = acc[8 + k]; acc[8 + k] = t; }
-    }
+    });
 }
 
 template <int TW, int TH, int NT, bool LIST>
