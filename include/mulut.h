@@ -122,7 +122,7 @@ int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap);
 int mulut_last_kernel_ms(mulut_ctx *ctx, float *ms, int cap);
 /* Work counters of the detailed-tile path of the last final-stage launch (scale 4; device -> host copy, synchronises with
  * `stream`): out[0..15] = samples (pixel x channel) per anchor MSB that went through the anchor-slab kernel,
- * out[16] = work items, out[17] = entries (samples, or border pixels with all their channels) on the fix-up list of that launch.  Returns the number of values written
+ * out[16] = work items, out[17] = pixels on the fix-up list of that launch.  Returns the number of values written
  * (0 when the path has not run).  For tests and the bench report; the reference has no counterpart. */
 int mulut_last_detail_counters(mulut_ctx *ctx, uint32_t *out, int cap, void *stream);
 
