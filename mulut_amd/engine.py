@@ -194,7 +194,7 @@ class MuLUTEngine:
 
     def last_detail_counters(self):
         """Work counters of the detailed-tile path of the last final-stage launch: dict with the samples per anchor MSB that
-        went through the anchor-slab kernel, the number of work items and the length of the pixel fix-up list."""
+        went through the anchor-slab kernel, the number of work items and the length of the fix-up list (entries: samples)."""
         buf = (ctypes.c_uint32 * 32)()
         n = self._lib.mulut_last_detail_counters(self._h, buf, 32, self._stream())
         if n < 0:
