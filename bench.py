@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--skip-other", action="store_true", help="do not also time the other input distributions")
     ap.add_argument("--skip-strips", action="store_true", help="N > 1: do not also time the strips + gather sharding (config 3)")
     ap.add_argument("--strip-frames", type=int, default=4, help="LR 2160x3840 frames per step of the strips + gather leg")
+    ap.add_argument("--strips-timeout", type=int, default=240, help="seconds the strips + gather leg may take before the headline is printed without it")
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="2: headline (2-stage sdy x4); 4: LUT fine-tune step (fwd + bwd + Adam, bs 256 x 1x48x48); "
                          "5: deep cascade (4-stage sdy x2, seeded synthetic tables), eager vs hipGraph")
@@ -264,16 +265,6 @@ def main():
             others[other] = world * F * H * SCALE * W * SCALE * max(2, args.steps // 2) / el2 / 1e6
             del x2
 
-    # config 3: LR 2160x3840 frames.  N = 1: whole frames on the one GPU.  N > 1: every frame cut into one strip per rank
-    # (+halo), cascade per strip, HR strips sent point to point (RCCL) into the frame on rank 0; the gather of batch k
-    # overlaps the compute of batch k + 1.
-    strips = None
-    if not args.skip_strips:
-        try:
-            strips = config3(args, eng, world, rank, dist_on, backend, timed)
-        except Exception as exc:      # the headline line must not depend on this leg
-            strips = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
-
     if rank == 0:
         sites = F * H * W * 3                                   # LR samples per launch
         lut_bytes = 3 * 83521 * (1 + SCALE * SCALE)             # every table read once: SURVEY 8(d) LUT_bytes
@@ -321,11 +312,44 @@ def main():
                          "first_stage_kernel_ms": round(float(ms_kernel[0]), 4),
                          "secondary": secondary},
         }
-        if strips:
-            rec["config"]["strips_gather"] = strips
         if cpu_rec is not None:
             rec["cpu_baseline"] = cpu_rec
-        print(json.dumps(rec))
+
+    # config 3: LR 2160x3840 frames.  N = 1: whole frames on the one GPU.  N > 1: every frame cut into one strip per rank
+    # (+halo), cascade per strip, HR strips sent point to point (RCCL) into the frame on rank 0; the gather of batch k
+    # overlaps the compute of batch k + 1.  The headline record is complete before this leg starts and cannot be lost to
+    # it: an exception is recorded, and a watchdog prints the record without the leg (and ends every rank) if the exchange
+    # has not come back in time.
+    strips = None
+    if not args.skip_strips:
+        import threading
+        lock, state = threading.Lock(), {"printed": False}
+
+        def give_up():
+            with lock:
+                if state["printed"]:
+                    return
+                state["printed"] = True
+                if rank == 0:
+                    rec["config"]["strips_gather"] = {"error": "no result within %d s; headline printed without it" % args.strips_timeout}
+                    print(json.dumps(rec), flush=True)
+            os._exit(0)
+        timer = threading.Timer(args.strips_timeout, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            strips = config3(args, eng, world, rank, dist_on, backend, timed)
+        except Exception as exc:      # the headline line must not depend on this leg
+            strips = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        timer.cancel()
+        with lock:
+            if state["printed"]:      # the watchdog fired while the leg was finishing: it owns the output
+                return
+            state["printed"] = True
+    if rank == 0:
+        if strips:
+            rec["config"]["strips_gather"] = strips
+        print(json.dumps(rec), flush=True)
     if dist_on:
         torch.distributed.destroy_process_group()
 
