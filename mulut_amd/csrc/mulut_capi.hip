@@ -55,6 +55,10 @@ struct mulut_ctx {
     uint16_t *det_thist = nullptr;
     uint4 *det_blocks = nullptr;
     size_t det_items_cap = 0, det_ids_cap = 0, det_blocks_cap = 0, det_tiles_cap = 0;
+    bool k1_valid = false;         // ctx->tlist holds the marks of the first-stage launch that produced the next stage's input ...
+    int k1_N = 0, k1_W = 0, k1_tiles_x = 0, k1_tiles_y = 0, k1_oy0 = 0;   // ... of this shape ...
+    const uint8_t *k1_out = nullptr;                                      // ... written to this buffer
+    int stat_from_k1 = 1;          // tuning "stat_from_first_stage": the final stage's statistic looks only at tiles the first stage marked
     int dirty_to_slab = 0;         // tuning "dirty_to_slab": 1 = the tube kernel's dirty samples are computed by the anchor-slab kernels, 0 = by the fix-up kernel
                                    // (measured on D-natural, 0.9 % dirty samples: 244 vs 226 us/frame -- the extra items cost the slab kernel a second
                                    // round of ~50 us, more than the gathers of the fix-up kernel; kept as an option)
@@ -456,6 +460,9 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.tiles_x = (W + tw - 1) / tw;
     a.tiles_y = (oy1 - oy0 + th - 1) / th;
     if (u == 1 && last) a.use_fma = 0;     // (a final stage with 1-byte rows -- scale 1 -- takes the integer epilogue)
+    // marks of the first-stage launch that produced this stage's input (same buffer, same shape); consumed here, never kept
+    const bool k1_marks = ctx->k1_valid && ctx->k1_out == in.p && ctx->k1_N == N && ctx->k1_W == W && ctx->k1_oy0 <= oy0;
+    ctx->k1_valid = false;
     if (u == 1) {
         const bool tube1 = (ctx->first_kernel == 0 || ctx->first_kernel == 3) && ctx->n_modes <= 3 &&
                            (unsigned long long)N * C * H * W < (1ull << 32);
@@ -482,6 +489,9 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         MAIN_KERNEL(ctx, stage, st, launch_stage_u1t(a, b1, (unsigned)ctx->u1_detail_per_1024, ctx->num_cus, st));
         if (route) HIP_TRY(ctx, launch_stage_u1w_list(a, ctx->num_cus, st));
         HIP_TRY(ctx, launch_stage_u1_fix(a, ctx->num_cus, st));
+        ctx->k1_valid = route;
+        ctx->k1_N = N; ctx->k1_W = W; ctx->k1_tiles_x = a.tiles_x; ctx->k1_tiles_y = a.tiles_y; ctx->k1_oy0 = oy0;
+        ctx->k1_out = out.p;
         return MULUT_OK;
     }
     int mode = kOutGeneric;
@@ -541,7 +551,12 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
             HIP_TRY(ctx, launch_site_flags(a, ctx->verdict, ctx->sflags, (uint32_t)ctx->hybrid_oob_per_1024, st));
             a.site_flags = ctx->sflags;
         } else {
+            if (ctx->stat_from_k1 && k1_marks) {
+                a.k1_hdr = ctx->tlist;
+                a.k1_tiles_x = ctx->k1_tiles_x; a.k1_tiles_y = ctx->k1_tiles_y; a.k1_oy0 = ctx->k1_oy0;
+            }
             HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st, slab ? ctx->det_thist : nullptr));
+            a.k1_hdr = nullptr;
         }
         a.verdict = ctx->verdict;
         a.vt_x = a.tiles_x;
@@ -850,6 +865,11 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "first_stage_kernel")) {
         if (value < 0 || value > 3) return MULUT_EINVAL;
         ctx->first_kernel = value;
+        return MULUT_OK;
+    }
+    if (!strcmp(key, "stat_from_first_stage")) {
+        if (value < 0 || value > 1) return MULUT_EINVAL;
+        ctx->stat_from_k1 = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "dirty_to_slab")) {

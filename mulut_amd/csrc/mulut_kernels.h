@@ -48,6 +48,11 @@ struct StageArgs {
     const uint32_t *verdict;
     int verdict_take;
     int vt_x, vt_y;         // verdict grid (64x16 tiles) per image
+    // final stage, optional: the tile list header of the first-stage tube kernel that produced this stage's input ([2] != 0: it
+    // routed by content, [16 + tile] = marked 64x64 tile of its grid): tile_stat_kernel calls the tiles it left unmarked smooth
+    // without looking at them
+    const uint32_t *k1_hdr;
+    int k1_tiles_x, k1_tiles_y, k1_oy0;
     // tube kernel: pixels with a pass outside the tube are appended here (id = (n H + y) W + x) and recomputed by
     // stage_up_fix_kernel; *fix_count is zeroed by the host side before the stage
     uint32_t *fix_list;

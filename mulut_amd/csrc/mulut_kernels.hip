@@ -839,6 +839,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
         if (a.verdict_take >= 0 && (hwc3 || planar)) {
             // routing statistic on every fourth row, before the tile is loaded: the share of four-pixel groups that span
             // more than one MSB step.  A detailed tile is handed to the full-table kernel without being staged here.
+            if (tile == 0 && threadIdx.x == 0 && a.tile_count) a.tile_count[2] = 1u;      // "the marks mean something" (for the final stage's statistic)
             uint32_t far = 0, seen = 0;
             if (hwc3) {
                 for (int i = threadIdx.x; i < (PH / 4) * GR; i += NT) {
@@ -1117,6 +1118,15 @@ __global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *v
     int n, y0, x0;
     const int id = xcd_remap(blockIdx.x, gridDim.x);   // neighbouring tiles on one XCD: halo lines fetched once
     decode_tile(a, id, n, y0, x0, TW, TH);
+    if (a.k1_hdr && a.k1_hdr[2] != 0u) {
+        // the statistic folded into the first stage: its tube kernel routed its 64x64 tiles by the detail of ITS input, and what it
+        // left unmarked is smooth enough here too (a wrong guess costs fix-up work, never exactness)
+        const int k1 = (n * a.k1_tiles_y + (y0 - a.k1_oy0) / 64) * a.k1_tiles_x + x0 / 64;
+        if (a.k1_hdr[16 + k1] == 0u) {          // workgroup-uniform
+            if (threadIdx.x == 0) verdict[id] = 0u;
+            return;
+        }
+    }
     if (threadIdx.x == 0) { s_cnt = 0; s_valid = 0; }
     const int total = a.C * PH * PW;
     const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;

@@ -69,6 +69,7 @@ def main():
         e.set_tuning("tube_site_flags", int(rng.integers(0, 2)))
         e.set_tuning("detail_kernel", int(rng.integers(0, 4) == 0))      # mostly the anchor-slab kernel (the default)
         e.set_tuning("dirty_to_slab", int(rng.integers(0, 3) == 0))      # an option (default off)
+        e.set_tuning("stat_from_first_stage", int(rng.integers(0, 4) != 0))      # mostly on (the default)
         e.set_tuning("first_stage_detail_per_1024", int(rng.choice([0, 64, 256, 1024])))
         n = int(rng.integers(1, 4))
         imgs = np.stack([content(rng, int(rng.integers(0, 5)), h, w, C) for _ in range(n)])
