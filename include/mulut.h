@@ -122,7 +122,7 @@ int mulut_last_stage_ms(mulut_ctx *ctx, float *ms, int cap);
 int mulut_last_kernel_ms(mulut_ctx *ctx, float *ms, int cap);
 /* Work counters of the detailed-tile path of the last final-stage launch (scale 4; device -> host copy, synchronises with
  * `stream`): out[0..15] = samples (pixel x channel) per anchor MSB that went through the anchor-slab kernel,
- * out[16] = work items, out[17] = pixels on the fix-up list of that launch.  Returns the number of values written
+ * out[16] = work items, out[17] = entries (samples, or border pixels with all their channels) on the fix-up list of that launch.  Returns the number of values written
  * (0 when the path has not run).  For tests and the bench report; the reference has no counterpart. */
 int mulut_last_detail_counters(mulut_ctx *ctx, uint32_t *out, int cap, void *stream);
 
@@ -161,6 +161,8 @@ int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int
  *   device, stage_slab_kernel; taken when the stage input is planar, < 2^28 bytes, <= 3 modes), 1 = full-table gather kernel.
  * "dirty_to_slab": 1 = the tube kernel's flagged samples are computed by the anchor-slab kernels too, 0 (default) = by the
  *   fix-up kernel from the full tables.
+ * "stat_from_first_stage": 1 (default) = when the final stage reads what a content-routing first-stage launch of the same
+ *   call wrote, its per-tile statistic looks only at the tiles that launch marked detailed; 0 = at every tile.
  * "hybrid_oob_per_1024": tile threshold of the hybrids (sites out of band per 1024, default 128).
  * "first_stage_kernel" (stages with 1-byte rows): 0 = auto (tube kernel; tiles its statistic calls detailed go to the
  *   window kernel, flagged sites are recomputed through a device work list), 1 = one LDS read per neighbour, full table in
