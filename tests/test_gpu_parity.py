@@ -343,6 +343,11 @@ def test_hybrid_final_stage_variants_agree_and_capture(eng, shipped_luts):
             eng.set_tuning("hybrid_oob_per_1024", thr)
         assert torch.equal(eng.pipeline(x), want), (sel, thr)
     eng.set_tuning("hybrid_oob_per_1024", 128).set_tuning("final_stage_kernel", 0)
+    for key in ("stat_from_first_stage", "dirty_to_slab", "detail_kernel"):       # the routing / work-list options of the default path
+        for val in (0, 1):
+            eng.set_tuning(key, val)
+            assert torch.equal(eng.pipeline(x), want), (key, val)
+    eng.set_tuning("stat_from_first_stage", 1).set_tuning("dirty_to_slab", 0).set_tuning("detail_kernel", 0)
     eng.set_tuning("first_stage_kernel", 1)                 # first stage: one-read-per-neighbour kernel == window kernel
     assert torch.equal(eng.pipeline(x), want)
     eng.set_tuning("first_stage_kernel", 0)
