@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
     const int G = (int)gridDim.x;
     // few marked tiles (fewer than half the workgroups): the unit of work is one CHANNEL of a tile, so that the launch does
     // not last as long as one whole tile (100 us) while most CUs have nothing to do
-    const int nsub = (listed && a.tile_count && *a.tile_count * 2u < (uint32_t)G) ? a.C : 1;       // workgroup-uniform
+    const int nsub = (listed && a.tile_count && *a.tile_count * 16u < (uint32_t)G) ? a.C : 1;       // workgroup-uniform (the count is of every eighth marked tile)
     const int nu_all = nt_all * nsub;
     const bool by_xcd = (G & 7) == 0;
     const int per = (nu_all + 7) >> 3;
@@ -865,7 +865,8 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                     a.tile_list[tile] = 1u;
                     // counted only while few: the list kernel asks "fewer than half the workgroups?", and on detailed content tens of
                     // thousands of atomics on one address would be a cost of their own
-                    if (a.tile_count && __hip_atomic_load(a.tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1024u) atomicAdd(a.tile_count, 1u);
+                    // (every eighth tile is counted -- an estimate is enough -- and only up to what the question needs)
+                    if (a.tile_count && (tile & 7) == 0 && __hip_atomic_load(a.tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 20u) atomicAdd(a.tile_count, 1u);
                 }
                 continue;
             }
@@ -2747,6 +2748,15 @@ __global__ void __launch_bounds__(256) detail_fill_kernel(StageArgs a, DetailArg
         if (threadIdx.x == 16) s_fix[0] = 0;
         __syncthreads();
         uint32_t pos[PER], fixr[4];
+        uint8_t val[PER];
+        // every byte of the thread in flight before the first LDS atomic (behind the per-sample condition each load would be
+        // a round trip of its own: twelve in a row)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int s = (int)threadIdx.x + k * 256;
+            const int c = imin(s >> 10, a.C - 1), y = imin(y0 + ((s >> 6) & 15), a.oy1 - 1), x = imin(x0 + (s & 63), a.W - 1);
+            val[k] = *view_addr(a.in, n, c, y, x);
+        }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int s = (int)threadIdx.x + k * 256;
@@ -2756,7 +2766,7 @@ __global__ void __launch_bounds__(256) detail_fill_kernel(StageArgs a, DetailArg
             const bool slab = inside && x >= kSlabXLo && x < a.W - slab_x_hi(a);
             pos[k] = 0xFFFFFFFFu;
             if (slab) {
-                const uint32_t h = (uint32_t)(*view_addr(a.in, n, c, y, x) >> 4);
+                const uint32_t h = (uint32_t)(val[k] >> 4);
                 pos[k] = s_base[h] + atomicAdd(&s_rank[h], 1u);
             }
             if (k < 4) fixr[k] = (inside && !slab) ? atomicAdd(&s_fix[0], 1u) : 0xFFFFFFFFu;      // k < 4 <=> channel 0: each pixel once
