@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
     const int G = (int)gridDim.x;
     // few marked tiles (fewer than half the workgroups): the unit of work is one CHANNEL of a tile, so that the launch does
     // not last as long as one whole tile (100 us) while most CUs have nothing to do
-    const int nsub = (listed && a.tile_count && *a.tile_count * 16u < (uint32_t)G) ? a.C : 1;       // workgroup-uniform (the count is of every eighth marked tile)
+    const int nsub = (listed && a.tile_count && *a.tile_count * 2u < (uint32_t)G) ? a.C : 1;       // workgroup-uniform
     const int nu_all = nt_all * nsub;
     const bool by_xcd = (G & 7) == 0;
     const int per = (nu_all + 7) >> 3;
@@ -865,8 +865,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                     a.tile_list[tile] = 1u;
                     // counted only while few: the list kernel asks "fewer than half the workgroups?", and on detailed content tens of
                     // thousands of atomics on one address would be a cost of their own
-                    // (every eighth tile is counted -- an estimate is enough -- and only up to what the question needs)
-                    if (a.tile_count && (tile & 7) == 0 && __hip_atomic_load(a.tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 20u) atomicAdd(a.tile_count, 1u);
+                    if (a.tile_count && __hip_atomic_load(a.tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 160u) atomicAdd(a.tile_count, 1u);
                 }
                 continue;
             }
