@@ -562,6 +562,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.vt_x = a.tiles_x;
         a.vt_y = a.tiles_y;
         a.verdict_take = 0;
+        if (tube && slab && ctx->dirty_to_slab && !ctx->dirty) HIP_TRY(ctx, hipMalloc((void **)&ctx->dirty, (ctx->fix_cap + 16) * sizeof(uint32_t)));
         if (tube && slab && ctx->dirty_to_slab) {
             // the tube kernel's dirty samples go on their own list: the anchor-slab kernels compute them with the detailed tiles
             HIP_TRY(ctx, hipMemsetAsync(ctx->dirty, 0, sizeof(uint32_t), st));
@@ -623,11 +624,10 @@ static int ensure_workspace(mulut_ctx *ctx, size_t bytes) {
 static int ensure_fix(mulut_ctx *ctx, size_t ids) {
     if (ids <= ctx->fix_cap) return MULUT_OK;
     if (ctx->fix) HIP_TRY(ctx, hipFree(ctx->fix));
-    if (ctx->dirty) HIP_TRY(ctx, hipFree(ctx->dirty));
+    if (ctx->dirty) HIP_TRY(ctx, hipFree(ctx->dirty));      // (sized like fix; reallocated on demand by the dirty_to_slab option)
     ctx->fix = ctx->dirty = nullptr;
     ctx->fix_cap = 0;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->fix, (ids + 16) * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->dirty, (ids + 16) * sizeof(uint32_t)));
     ctx->fix_cap = ids;
     return MULUT_OK;
 }
@@ -724,7 +724,8 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
                 memset(&t, 0, sizeof(t));
                 t.N = N; t.tiles_x = (W + tw - 1) / tw; t.tiles_y = (H + th - 1) / th;
                 t.in.sN = (long long)H * W * C;
-                if ((long long)t.N * t.tiles_x * t.tiles_y < (1ll << 20)) {
+                t.in.sX = 1; t.C = C; t.M = ctx->n_modes; t.H = H; t.W = W;
+                if (detail_slab_supported(t)) {       // launches of this size that the anchor-slab path would take
                     rc = ensure_detail(ctx, (size_t)t.N * t.tiles_x * t.tiles_y, detail_items_max(t), detail_ids_count(t), detail_blocks_count(t));
                     if (rc) return rc;
                 }
