@@ -59,6 +59,7 @@ struct mulut_ctx {
     int k1_N = 0, k1_W = 0, k1_tiles_x = 0, k1_tiles_y = 0, k1_oy0 = 0;   // ... of this shape ...
     const uint8_t *k1_out = nullptr;                                      // ... written to this buffer
     int stat_from_k1 = 1;          // tuning "stat_from_first_stage": the final stage's statistic looks only at tiles the first stage marked
+    int tube2 = 1;                 // tuning "tube_pipelined": 1 = stage_tube2_kernel (hand-scheduled LDS reads) where the mode list has one, 0 = stage_tube_kernel
     int dirty_to_slab = 0;         // tuning "dirty_to_slab": 1 = the tube kernel's dirty samples are computed by the anchor-slab kernels, 0 = by the fix-up kernel
                                    // (measured on D-natural, 0.9 % dirty samples: 244 vs 226 us/frame -- the extra items cost the slab kernel a second
                                    // round of ~50 us, more than the gathers of the fix-up kernel; kept as an option)
@@ -425,6 +426,11 @@ static int ensure_tlist(mulut_ctx *ctx, size_t tiles);
 static int ensure_sflags(mulut_ctx *ctx, size_t bytes);
 static int ensure_detail(mulut_ctx *ctx, size_t tiles, size_t items, size_t ids, size_t blocks);
 
+static hipError_t tube_launch(mulut_ctx *ctx, const StageArgs &a, const BandArgs &b, int mode, hipStream_t st) {
+    if (ctx->tube2 && stage_tube2_supported(a)) return launch_stage_tube2(a, b, mode, ctx->num_cus, st);
+    return launch_stage_tube(a, b, mode, ctx->num_cus, st);
+}
+
 // Launch one stage: input view holds LR rows [in.row0, ...), outputs for LR rows [oy0, oy1).
 static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
                      int C, int oy0, int oy1, hipStream_t st) {
@@ -570,8 +576,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
             StageArgs t = a;
             t.fix_count = ctx->dirty;
             t.fix_list = ctx->dirty + 16;
-            MAIN_KERNEL(ctx, stage, st, launch_stage_tube(t, b, mode, ctx->num_cus, st));
-        } else if (tube) MAIN_KERNEL(ctx, stage, st, launch_stage_tube(a, b, mode, ctx->num_cus, st));
+            MAIN_KERNEL(ctx, stage, st, tube_launch(ctx, t, b, mode, st));
+        } else if (tube) MAIN_KERNEL(ctx, stage, st, tube_launch(ctx, a, b, mode, st));
         else MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
         if (slab) {
             DetailArgs d;
@@ -600,7 +606,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
             HIP_TRY(ctx, launch_site_flags(a, nullptr, ctx->sflags, 0u, st));
             a.site_flags = ctx->sflags;
         }
-        MAIN_KERNEL(ctx, stage, st, launch_stage_tube(a, b, mode, ctx->num_cus, st));
+        MAIN_KERNEL(ctx, stage, st, tube_launch(ctx, a, b, mode, st));
         HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
     } else if (x) MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
     else MAIN_KERNEL(ctx, stage, st, launch_stage_band(a, b, mode, ctx->num_cus, st));
@@ -871,6 +877,11 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "stat_from_first_stage")) {
         if (value < 0 || value > 1) return MULUT_EINVAL;
         ctx->stat_from_k1 = value;
+        return MULUT_OK;
+    }
+    if (!strcmp(key, "tube_pipelined")) {
+        if (value < 0 || value > 1) return MULUT_EINVAL;
+        ctx->tube2 = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "dirty_to_slab")) {

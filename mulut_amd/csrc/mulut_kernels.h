@@ -132,6 +132,10 @@ const char *stage_bandx_name(int out_mode);
 // mode m (LO plane then HI plane, kTubeBandBytes); no band swaps, channel-outer loops
 hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 const char *stage_tube_name(int out_mode);
+// the same kernel with every LDS read hand-scheduled (rows of the next pass in flight under the current pass's MACs); built for
+// the mode lists stage_tube2_supported() accepts
+bool stage_tube2_supported(const StageArgs &a);
+hipError_t launch_stage_tube2(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 // recompute the pixels listed in a.fix_list[0 .. *a.fix_count) from the full tables (u == 4)
 hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st);
 // detailed tiles (a.verdict[tile] == 1, 64x16 tiling) of a u == 4 final stage from anchor slabs in LDS: bucket, plan,

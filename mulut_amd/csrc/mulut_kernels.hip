@@ -2563,6 +2563,325 @@ hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode
 }
 
 // ------------------------------------------------------------------------------------------
+// K2-tube2: the tube kernel with every LDS read hand-scheduled (tools/gen_tube2_asm.py -> mulut_tube2_asm.inc).
+// Same LDS image, same arithmetic, same fix-up list as stage_tube_kernel; what changes is WHEN things are issued:
+//   * the five rows of a pass live in 40 VGPRs above the compiler's register budget, so the ten ds_read_b128 of the
+//     NEXT pass are in flight while the current pass's 40 v_pk_mad_u16 run (a row's registers are refilled right after
+//     its eight MACs); the neighbour codes of the pair after next are fetched under the MACs of a pair's second pass;
+//   * the index math of a pair (compiler-scheduled C++ between the blocks) therefore never waits for LDS;
+//   * the pipeline runs on across the channels of a site; it drains once per tile (one site per thread and tile).
+// Pixel codes are code1 (f << 12 | h): a sort key is code | stride (one OR), the slot sum a v_pk_mad_u16 chain on the
+// raw codes (the LSB nibble multiplies out of the 16-bit half), as in the first-stage tube kernel.
+// The mode list is a template parameter (PATS = M | p0 << 2 | p1 << 4 | p2 << 6): every neighbour offset and band offset is
+// an immediate.  Instantiated for the mode strings launch_stage_tube2 lists; the others take stage_tube_kernel.
+// ------------------------------------------------------------------------------------------
+#if defined(MULUT_VARIANT_t2dbg1)
+#include "mulut_tube2_asm_dbg1.inc"
+#elif defined(MULUT_VARIANT_t2dbg2)
+#include "mulut_tube2_asm_dbg2.inc"
+#elif defined(MULUT_VARIANT_t2dbg3)
+#include "mulut_tube2_asm_dbg3.inc"
+#else
+#include "mulut_tube2_asm.inc"
+#endif
+
+struct T2Pair {
+    uint32_t base, s0, s1, s2;      // packed per pass: byte offset of row 0 (+ bias), byte strides of path steps 1..3
+    uint32_t w0, w1, w2, w3, w4;    // packed weights
+};
+__host__ __device__ constexpr int t2_modes(int pats) { return pats & 3; }
+__host__ __device__ constexpr int t2_pat(int pats, int m) { return (pats >> (2 + 2 * m)) & 3; }
+constexpr int kTube2LdsBytes = kTubeLdsBytes + 2 * 16 * KB_TW * KB_TH;      // + the parked output rows of channels 0 and 1 (RGB path)
+static_assert(kTube2LdsBytes <= 160 * 1024, "LDS budget");
+constexpr int kT2PW = KB_TW + 2 * kTubeHaloX, kT2PH = KB_TH + 2 * kHalo, kT2Chan = 2 * kT2PH * kT2PW;
+// byte offset (from the window corner) of neighbour K of pattern PAT under rotation R; SIGN -1: rotation R + 2
+__host__ __device__ constexpr int t2_nb(int pat, int r, int k, int sign) {
+    return 2 * ((2 + sign * rot_dy(r, kPatDi[pat][k], kPatDj[pat][k])) * kT2PW + 2 + sign * rot_dx(r, kPatDi[pat][k], kPatDj[pat][k]));
+}
+__host__ __device__ constexpr int t2_imm(int pat) { return pat * kTubeBandBytes - tube_bias(pat); }
+
+template <int PAT>
+__device__ __forceinline__ void t2_index(uint32_t k0, uint32_t ha, uint32_t base_a0, uint32_t pb, uint32_t pc, uint32_t pd, T2Pair &o, uint32_t &dirty) {
+    constexpr uint32_t SB = kTubeSB * 16, SC = kTubeSC * 16, SD = kTubeSD * 16;
+    uint32_t k1 = pb | pk_dup(SB), k2 = pc | pk_dup(SC), k3 = pd | pk_dup(SD);
+    const uint32_t hb = pb & 0x000F000Fu, hc = pc & 0x000F000Fu, hd = pd & 0x000F000Fu;
+    pk_cmpx_desc(k0, k1);
+    pk_cmpx_desc(k2, k3);
+    pk_cmpx_desc(k0, k2);
+    pk_cmpx_desc(k1, k3);
+    pk_cmpx_desc(k1, k2);
+    const uint32_t f1 = pk_shr12(k0), f2 = pk_shr12(k1), f3 = pk_shr12(k2), f4 = pk_shr12(k3);
+    // code * (16 * stride) = 16 * h * stride per half: the f nibble (bits 12..15) times a multiple of 16 leaves the half
+    o.base = pk_mad(pb, pk_dup(SB), pk_mad(pc, pk_dup(SC), pk_mad(pd, pk_dup(SD), base_a0 + pk_dup((uint32_t)tube_bias(PAT)))));
+    o.s0 = k0 & 0x0FF00FF0u;
+    o.s1 = k1 & 0x0FF00FF0u;
+    o.s2 = k2 & 0x0FF00FF0u;
+    o.w0 = pk_dup(kQ) - f1;
+    o.w1 = f1 - f2;
+    o.w2 = f2 - f3;
+    o.w3 = f3 - f4;
+    o.w4 = f4;
+    const uint32_t mx = pk_max(pk_max(hb, hc), pk_max(hd, ha));
+    const uint32_t mn = pk_min(pk_min(hb, hc), pk_min(hd, ha));
+    dirty |= (mx - mn) & 0xFFFEFFFEu;       // in the tube iff the MSBs span at most one step
+}
+
+#define T2_ACC_OPS(lo, hi) [l0] "+v"(lo[0]), [l1] "+v"(lo[1]), [l2] "+v"(lo[2]), [l3] "+v"(lo[3]), [h0] "+v"(hi[0]), [h1] "+v"(hi[1]), [h2] "+v"(hi[2]), [h3] "+v"(hi[3])
+#define T2_TMP_OPS [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+#define T2_W_OPS(c) [w0] "v"(c.w0), [w1] "v"(c.w1), [w2] "v"(c.w2), [w3] "v"(c.w3), [w4] "v"(c.w4)
+#define T2_ADDR_OPS(n) [base] "v"(n.base), [s0] "v"(n.s0), [s1] "v"(n.s1), [s2] "v"(n.s2)
+#define T2_IMM_OPS(PAT) [ilo] "i"(t2_imm(PAT)), [ihi] "i"(t2_imm(PAT) + kTubePlaneBytes), [ilo4] "i"(t2_imm(PAT) + kTubeAll * 16), [ihi4] "i"(t2_imm(PAT) + kTubeAll * 16 + kTubePlaneBytes)
+#define T2_NB_OPS(PAT, R, OFF) [n0] "i"(t2_nb(PAT, R, 0, 1) + (OFF)), [n1] "i"(t2_nb(PAT, R, 0, -1) + (OFF)), [n2] "i"(t2_nb(PAT, R, 1, 1) + (OFF)), \
+    [n3] "i"(t2_nb(PAT, R, 1, -1) + (OFF)), [n4] "i"(t2_nb(PAT, R, 2, 1) + (OFF)), [n5] "i"(t2_nb(PAT, R, 2, -1) + (OFF)), [nan] "i"(2 * (2 * kT2PW + 2) + (OFF))
+
+#define T2_NBOUT_OPS [pb] "=&v"(pb), [pc] "=&v"(pc), [pd] "=&v"(pd), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+// first pass of a pair (weights = low halves of cur): MACs, refill with the pair's second pass
+template <int PAT>
+__device__ __forceinline__ void t2_block_a(uint32_t (&lo)[4], uint32_t (&hi)[4], const T2Pair &cur) {
+    uint32_t a0, a1, a2, a3;
+    asm volatile(TUBE2_ASM_A : T2_ACC_OPS(lo, hi), T2_TMP_OPS : T2_W_OPS(cur), T2_ADDR_OPS(cur), T2_IMM_OPS(PAT) : TUBE2_CLOBBERS);
+}
+// second pass (weights = high halves of cur, reversed element order): MACs, refill with the first pass of the next pair (pattern
+// NPAT, addresses from nxt).  NN: neighbour codes fetched under the MACs -- 0 none, 6 those of rotation pair TR of pattern TPAT in the
+// window at win + TOFF (out: pb, pc, pd), 7 the same + that window's anchor code (out: ca, in both halves).
+// LAST: no refill (the site's very last pass).
+template <int NPAT, int NN, int TPAT, int TR, int TOFF, bool LAST>
+__device__ __forceinline__ void t2_block_b(uint32_t (&lo)[4], uint32_t (&hi)[4], const T2Pair &cur, const T2Pair &nxt, uint32_t win,
+                                           uint32_t &pb, uint32_t &pc, uint32_t &pd, uint32_t &ca) {
+    uint32_t a0, a1, a2, a3, t0, t1, t2;
+    if constexpr (LAST)
+        asm volatile(TUBE2_ASM_B_LAST : T2_ACC_OPS(lo, hi) : T2_W_OPS(cur) : TUBE2_CLOBBERS);
+    else if constexpr (NN == 0)
+        asm volatile(TUBE2_ASM_B_N0 : T2_ACC_OPS(lo, hi), T2_TMP_OPS : T2_W_OPS(cur), T2_ADDR_OPS(nxt), T2_IMM_OPS(NPAT) : TUBE2_CLOBBERS);
+    else if constexpr (NN == 6)
+        asm volatile(TUBE2_ASM_B_N6 : T2_ACC_OPS(lo, hi), T2_TMP_OPS, T2_NBOUT_OPS : T2_W_OPS(cur), T2_ADDR_OPS(nxt), T2_IMM_OPS(NPAT), [win] "v"(win), T2_NB_OPS(TPAT, TR, TOFF) : TUBE2_CLOBBERS);
+    else
+        asm volatile(TUBE2_ASM_B_N7 : T2_ACC_OPS(lo, hi), T2_TMP_OPS, T2_NBOUT_OPS, [ca] "=&v"(ca) : T2_W_OPS(cur), T2_ADDR_OPS(nxt), T2_IMM_OPS(NPAT), [win] "v"(win), T2_NB_OPS(TPAT, TR, TOFF) : TUBE2_CLOBBERS);
+}
+
+template <int OUT, int PATS>
+__global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_eu(TUBE2_WAVES_PER_EU, TUBE2_WAVES_PER_EU))) stage_tube2_kernel(StageArgs a, BandArgs b) {
+    constexpr int TW = KB_TW, TH = KB_TH, PW = kT2PW, PH = kT2PH, NT = TW * TH;
+    constexpr int M = t2_modes(PATS), NP = 2 * M;
+    constexpr int DW = PW / 4, PER4 = (3 * PH * DW + NT - 1) / NT;
+    static_assert(((2 * 3 * PH * PW + 15) / 16) * 16 == kTubeTileBytes, "tile buffer size");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    const int G = gridDim.x;
+    const bool by_xcd = (G & 7) == 0;
+    const int per = (ntiles + 7) >> 3;
+    const int first = by_xcd ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int last = by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, ntiles) : ntiles;
+    const int step = by_xcd ? (G >> 3) : G;
+    auto next_tile = [&](int t) {
+        if (a.verdict_take >= 0)
+            while (t < last && (int)a.verdict[t] != a.verdict_take) t += step;
+        return t;
+    };
+    const int total = a.C * PH * PW;
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    const bool dw_ok = a.in.sX == 1 && ((a.W | a.in.sY | a.in.sC) & 3) == 0 && (a.in.sN & 3) == 0 && (((uintptr_t)a.in.p) & 3) == 0;
+    auto fetch = [&](int tile, uint32_t (&v)[PER4]) {
+        if (!dw_ok) return;
+        int n, y0, x0;
+        decode_tile(a, tile, n, y0, x0, TW, TH);
+        int tid = (int)threadIdx.x;       // opaque: no per-thread term of this may stay live across a tile's computation
+        asm volatile("" : "+v"(tid));
+#pragma unroll
+        for (int k = 0; k < PER4; ++k) {
+            const int i = tid + k * NT;
+            const int q = i % DW, py = (i / DW) % PH, c = imin(i / (DW * PH), a.C - 1);
+            const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
+            const int gx = imin(imax(x0 - kTubeHaloX + 4 * q, 0), a.W - 4);
+            v[k] = *(const uint32_t *)view_addr(a.in, n, c, gy, gx);
+        }
+    };
+    auto stash = [&](int tile, int buf, const uint32_t (&v)[PER4]) {
+        int n, y0, x0;
+        decode_tile(a, tile, n, y0, x0, TW, TH);
+        uint8_t *dst = smem + 3 * kTubeBandBytes + buf * kTubeTileBytes;
+        if (dw_ok) {
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));
+#pragma unroll
+            for (int k = 0; k < PER4; ++k) {
+                const int i = tid + k * NT;
+                if (i < a.C * PH * DW) {
+                    const int gx = x0 - kTubeHaloX + 4 * (i % DW);
+                    const uint32_t sel_lo = gx < 0 ? 0x0C000C00u : gx > a.W - 4 ? 0x0C030C03u : 0x0C010C00u;
+                    const uint32_t sel_hi = gx < 0 ? 0x0C000C00u : gx > a.W - 4 ? 0x0C030C03u : 0x0C030C02u;
+                    const uint32_t lo = __builtin_amdgcn_perm(0u, v[k], sel_lo), hi = __builtin_amdgcn_perm(0u, v[k], sel_hi);
+                    // code1 per 16-bit lane: (b << 12) keeps the LSB nibble in bits 12..15, b >> 4 is the MSB nibble
+                    uint2 c2;
+                    c2.x = pk_mad(lo, pk_dup(0x1000u), pk_shr4(lo));
+                    c2.y = pk_mad(hi, pk_dup(0x1000u), pk_shr4(hi));
+                    *(uint2 *)(dst + 8 * i) = c2;
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < total; i += NT) {
+                const int px = i % PW, py = (i / PW) % PH, c = i / (PW * PH);
+                const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
+                const int gx = imin(imax(x0 + px - kTubeHaloX, 0), a.W - 1);
+                ((uint16_t *)dst)[i] = (uint16_t)pixel_code1(*view_addr(a.in, n, c, gy, gx));
+            }
+        }
+    };
+
+    int tile = next_tile(first);
+    if (tile >= last) return;              // workgroup-uniform
+    uint32_t pix[PER4];
+    fetch(tile, pix);
+    // bands: slot = pattern id of the mode; patterns the mode list lacks are never read
+    static_for<0, M>([&](auto MI) {
+        constexpr int pat = t2_pat(PATS, MI);
+        const uint4 *src = (const uint4 *)b.band[MI];
+        uint4 *dst = (uint4 *)(smem + pat * kTubeBandBytes);
+        for (int i = threadIdx.x; i < kTubeBandBytes / 16; i += NT) dst[i] = src[i];
+    });
+    stash(tile, 0, pix);
+    __syncthreads();
+
+    for (int it = 0; tile < last; ++it) {
+        const int nxt_tile = next_tile(tile + step);
+        if (nxt_tile < last) fetch(nxt_tile, pix);
+        int n, y0, x0;
+        decode_tile(a, tile, n, y0, x0, TW, TH);
+        int tid2 = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const int tx = tid2 % TW, ty = tid2 / TW;
+        const int y = y0 + ty, x = x0 + tx;
+        if (y < a.oy1 && x < a.W) {
+            // LDS byte address of the 5x5 window corner (y-2, x-2) of this site, channel 0
+            uint32_t win = (uint32_t)(3 * kTubeBandBytes + (it & 1) * kTubeTileBytes + 2 * (ty * PW + tx + kTubeHaloX - kHalo));
+            // finished channels wait in LDS for the RGB interleave (a uint4 per thread and channel): registers are what the
+            // pipelined loop below is short of
+            uint4 *park = (uint4 *)(smem + kTubeLdsBytes) + threadIdx.x;
+            uint32_t dmask = 0u, dirty = 0u, dirty_n = 0u;
+            uint32_t o[4] = {0u, 0u, 0u, 0u};
+            uint32_t pb, pc, pd, ca;
+            uint32_t k0, ha, ba0;
+            auto anchor = [&](uint32_t c2) {      // c2 = the anchor's code in both halves
+                k0 = (c2 & 0xF000F000u) | pk_dup((uint32_t)kTubeSA * 16);
+                ha = c2 & 0x000F000Fu;
+                ba0 = pk_mad(c2, pk_dup((uint32_t)kTubeSA * 16), 0u);
+            };
+            T2Pair cur, nxt;
+            {
+                constexpr int p0 = t2_pat(PATS, 0);
+                uint32_t t0, t1, t2;
+                asm volatile(TUBE2_ASM_LOAD_NB_ANCHOR : T2_NBOUT_OPS, [ca] "=&v"(ca) : [win] "v"(win), T2_NB_OPS(p0, 0, 0) : TUBE2_CLOBBERS);
+                anchor(ca);
+                t2_index<p0>(k0, ha, ba0, pb, pc, pd, cur, dirty);
+                asm volatile(TUBE2_ASM_LOAD_NB : T2_NBOUT_OPS : [win] "v"(win), T2_NB_OPS(p0, 1, 0) : TUBE2_CLOBBERS);
+                uint32_t a0, a1, a2, a3;
+                asm volatile(TUBE2_ASM_FIRST_ROWS : T2_TMP_OPS : T2_ADDR_OPS(cur), T2_IMM_OPS(p0) : TUBE2_CLOBBERS);
+                t2_index<p0>(k0, ha, ba0, pb, pc, pd, nxt, dirty);
+            }
+            RotAcc<4> acc;
+            acc.clear();
+#pragma clang loop unroll(disable)
+            for (int c = 0; c < a.C; ++c, win += kT2Chan) {
+                const bool more = c + 1 < a.C;       // wave-uniform
+                static_for<0, NP>([&](auto PI) {
+                    constexpr int p = PI;
+                    constexpr int pat = t2_pat(PATS, p >> 1), R = p & 1;
+                    // the pair whose neighbours are fetched now (two pairs ahead) and the pair whose first rows refill the registers
+                    constexpr bool t_here = p + 2 < NP;
+                    constexpr int tp = t_here ? p + 2 : p + 2 - NP, tpat = t2_pat(PATS, tp >> 1), tr = tp & 1, toff = t_here ? 0 : kT2Chan;
+                    constexpr bool n_here = p + 1 < NP;
+                    constexpr int npat = t2_pat(PATS, n_here ? (p + 1) >> 1 : 0);
+                    T2Pair nn;
+                    auto &lo = R == 0 ? acc.lo02 : acc.lo13;
+                    auto &hi = R == 0 ? acc.hi02 : acc.hi13;
+                    t2_block_a<pat>(lo, hi, cur);
+                    if (t_here || more) {      // (then the next pair exists too: t_here implies n_here)
+                        t2_block_b<npat, (tp == 0 ? 7 : 6), tpat, tr, toff, false>(lo, hi, cur, nxt, win, pb, pc, pd, ca);
+                        if constexpr (tp == 0) anchor(ca);
+                        if constexpr (t_here) t2_index<tpat>(k0, ha, ba0, pb, pc, pd, nn, dirty);
+                        else t2_index<tpat>(k0, ha, ba0, pb, pc, pd, nn, dirty_n);
+                    } else {
+                        if constexpr (n_here) t2_block_b<npat, 0, 0, 0, 0, false>(lo, hi, cur, nxt, win, pb, pc, pd, ca);
+                        else t2_block_b<npat, 0, 0, 0, 0, true>(lo, hi, cur, nxt, win, pb, pc, pd, ca);
+                        nn = nxt;
+                    }
+                    cur = nxt;
+                    nxt = nn;
+                });
+                if constexpr (OUT == kOutPackedRGBU4) {
+                    tube_finish_rows(a, acc, o);
+                    if (c < 2) park[c * NT] = make_uint4(o[0], o[1], o[2], o[3]);
+                } else {
+                    uint32_t o[4];
+                    finish_channel<4, OUT>(a, acc, n, c, y, x, o);
+                }
+                acc.clear();
+                dmask |= (dirty != 0u ? 1u : 0u) << c;
+                dirty = dirty_n;
+                dirty_n = 0u;
+            }
+            if constexpr (OUT == kOutPackedRGBU4) {
+                const uint4 r = park[0], g = park[NT];
+                const uint32_t oR[4] = {r.x, r.y, r.z, r.w}, oG[4] = {g.x, g.y, g.z, g.w};
+                store_rgb<4>(a, n, y, x, oR, oG, o);
+            }
+            if (__ballot(dmask != 0u) != 0ull) {
+                const uint32_t pixel_id = (uint32_t)((n * a.H + y) * a.W + x);
+                for (int c = 0; c < a.C; ++c) {
+                    const bool d = ((dmask >> c) & 1u) != 0u;
+                    const unsigned long long dm = __ballot(d);
+                    if (dm == 0ull) continue;
+                    const int lane = (int)(threadIdx.x & 63);
+                    uint32_t at = 0;
+                    if (lane == __ffsll((long long)dm) - 1) at = atomicAdd(a.fix_count, (uint32_t)__popcll(dm));
+                    at = (uint32_t)__shfl((int)at, __ffsll((long long)dm) - 1);
+                    if (d) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = pixel_id | ((uint32_t)c << 30);
+                }
+            }
+        }
+        if (nxt_tile < last) stash(nxt_tile, (it + 1) & 1, pix);
+        __syncthreads();     // next tile published; everyone is done reading the current one
+        tile = nxt_tile;
+    }
+}
+
+constexpr int kT2PatsSDY = 3 | (0 << 2) | (1 << 4) | (2 << 6);
+
+// pattern list of the launch as PATS (0 if the list is not one stage_tube2_kernel is built for)
+static int tube2_pats(const StageArgs &a) {
+    int pats = a.M;
+    for (int m = 0; m < a.M; ++m) pats |= (a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0) << (2 + 2 * m);
+    return pats == kT2PatsSDY ? pats : 0;
+}
+bool stage_tube2_supported(const StageArgs &a) { return a.C <= 3 && a.M <= 3 && a.site_flags == nullptr && tube2_pats(a) != 0; }
+
+template <int OUT>
+static hipError_t launch_tube2_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
+    auto kern = stage_tube2_kernel<OUT, kT2PatsSDY>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
+    if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(ntiles < num_cus ? ntiles : num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(KB_TW * KB_TH), (size_t)kTube2LdsBytes, st, a, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_tube2(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st) {
+    if (!stage_tube2_supported(a)) return hipErrorInvalidValue;
+    if (out_mode == kOutPlanarU4) return launch_tube2_t<kOutPlanarU4>(a, b, num_cus, st);
+    if (out_mode == kOutPackedRGBU4 && a.C == 3) return launch_tube2_t<kOutPackedRGBU4>(a, b, num_cus, st);
+    return launch_tube2_t<kOutGeneric>(a, b, num_cus, st);
+}
+
+// ------------------------------------------------------------------------------------------
 // Detailed tiles of the final stage (u == 4): anchor slabs in LDS instead of row gathers from L2.
 //
 // On detailed content the full-table kernel is bound by its gathers: 60 rows of 16 bytes per sample, nearly every one
