@@ -125,6 +125,12 @@ int mulut_last_kernel_ms(mulut_ctx *ctx, float *ms, int cap);
  * out[16] = work items, out[17] = entries (samples, or border pixels with all their channels) on the fix-up list of that launch.  Returns the number of values written
  * (0 when the path has not run).  For tests and the bench report; the reference has no counterpart. */
 int mulut_last_detail_counters(mulut_ctx *ctx, uint32_t *out, int cap, void *stream);
+/* Probe buffer of the context: MULUT_DEBUG_WORDS 64-bit words of device memory that only probe builds of the kernels
+ * (-DMULUT_VARIANT_...prof: in-kernel clock stamps per phase) write to -- never an output buffer, and no output value is computed
+ * from it.  Copies min(cap, MULUT_DEBUG_WORDS) words to `out` (synchronises with `stream`), then zeroes the buffer when
+ * `reset` != 0.  Returns the number of words copied.  The shipped library leaves the buffer at zero. */
+#define MULUT_DEBUG_WORDS 4096
+int mulut_debug_read(mulut_ctx *ctx, unsigned long long *out, int cap, int reset, void *stream);
 
 /* ---- LUT-aware fine-tuning (the differentiable twin; stateless, float32) -----------------------------
  * One stage of MuLUT.forward (sr/model.py:289-312) = InterpTorchBatch (:69-287) over all modes x 4 rotations

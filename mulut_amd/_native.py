@@ -9,7 +9,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 _LIBDIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(_LIBDIR, "libmulut_hip.so")
 SOURCES = ["mulut_kernels.hip", "mulut_capi.hip", "mulut_ft.hip", "mulut_eval.hip"]
-HEADERS = ["mulut_core.h", "mulut_kernels.h", os.path.join("..", "..", "include", "mulut.h")]
+HEADERS = ["mulut_core.h", "mulut_kernels.h", "mulut_tube2_asm.inc", os.path.join("..", "..", "include", "mulut.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall"]
 
 # every symbol include/mulut.h declares
@@ -18,7 +18,7 @@ EXPORTS = [
     "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage", "mulut_pipeline",
     "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing", "mulut_last_stage_ms", "mulut_last_kernel_ms",
     "mulut_set_tuning", "mulut_kernel_name", "mulut_ft_stage_forward", "mulut_ft_stage_backward",
-    "mulut_eval_ws_doubles", "mulut_eval_y", "mulut_last_detail_counters",
+    "mulut_eval_ws_doubles", "mulut_eval_y", "mulut_last_detail_counters", "mulut_debug_read",
 ]
 
 _libs = {}
@@ -105,6 +105,8 @@ def load(path=None):
     L.mulut_last_kernel_ms.argtypes = [p, ctypes.POINTER(ctypes.c_float), i]
     L.mulut_last_detail_counters.argtypes = [p, ctypes.POINTER(ctypes.c_uint32), i, p]
     L.mulut_last_detail_counters.restype = i
+    L.mulut_debug_read.argtypes = [p, ctypes.POINTER(ctypes.c_uint64), i, i, p]
+    L.mulut_debug_read.restype = i
     L.mulut_set_tuning.argtypes = [p, c_char_p, i]
     L.mulut_kernel_name.argtypes = [p, i]
     L.mulut_ft_stage_forward.argtypes = [i, p, c_char_p, i, i, p, i, i, i, i, p, p]

@@ -50,6 +50,7 @@ struct mulut_ctx {
     size_t fix_cap = 0;            // capacity in ids
     uint8_t *sflags = nullptr;     // site_flag_kernel's byte per pixel of the final-stage input
     size_t sflags_cap = 0;
+    unsigned long long *dbg = nullptr;   // probe buffer (mulut_debug_read), MULUT_DEBUG_WORDS words, allocated on first use
     uint32_t *det_ctl = nullptr;   // detailed-tile path of the final stage (launch_detail_slab): counters, items, sample ids, blocks
     uint32_t *det_items = nullptr, *det_desc = nullptr, *det_tpos = nullptr, *det_dlist = nullptr;
     uint16_t *det_thist = nullptr;
@@ -152,6 +153,7 @@ int mulut_destroy(mulut_ctx *ctx) {
     if (ctx->dirty) (void)hipFree(ctx->dirty);
     if (ctx->sflags) (void)hipFree(ctx->sflags);
     if (ctx->tlist) (void)hipFree(ctx->tlist);
+    if (ctx->dbg) (void)hipFree(ctx->dbg);
     if (ctx->det_ctl) (void)hipFree(ctx->det_ctl);
     if (ctx->det_items) (void)hipFree(ctx->det_items);
     if (ctx->det_desc) (void)hipFree(ctx->det_desc);
@@ -441,6 +443,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     const bool last = stage == ctx->stages;
     const int u = stage_u(ctx, stage);
     a.in = in; a.out = out;
+    a.dbg = ctx->dbg;
     a.in_padded = (in.p == ctx->ws[0] || in.p == ctx->ws[1]) ? 1 : 0;
     a.N = N; a.C = C; a.H = H; a.W = W;
     a.oy0 = oy0; a.oy1 = oy1;
@@ -859,6 +862,20 @@ int mulut_last_detail_counters(mulut_ctx *ctx, uint32_t *out, int cap, void *str
     if (n < cap) out[n++] = ctl[kDetItems];
     if (n < cap) out[n++] = fixn;
     for (int k = 48; k < 56 && n < cap; ++k) out[n++] = ctl[k];      // phase clocks of the slabclk probe build (zero otherwise)
+    return n;
+}
+
+int mulut_debug_read(mulut_ctx *ctx, unsigned long long *out, int cap, int reset, void *stream) {
+    if (!ctx || (cap > 0 && !out) || cap < 0) return MULUT_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->dbg) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->dbg, MULUT_DEBUG_WORDS * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemset(ctx->dbg, 0, MULUT_DEBUG_WORDS * sizeof(unsigned long long)));
+    }
+    const int n = cap < MULUT_DEBUG_WORDS ? cap : MULUT_DEBUG_WORDS;
+    if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(out, ctx->dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (reset) HIP_TRY(ctx, hipMemsetAsync(ctx->dbg, 0, MULUT_DEBUG_WORDS * sizeof(unsigned long long), (hipStream_t)stream));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     return n;
 }
 

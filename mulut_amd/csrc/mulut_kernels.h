@@ -63,6 +63,7 @@ struct StageArgs {
     // list mode); zeroed by the host side before the stage
     uint32_t *tile_list;
     uint32_t *tile_count;     // number of tiles marked in tile_list (the tube kernel counts, the list kernel sizes its work units by it)
+    unsigned long long *dbg;  // the context's probe buffer (MULUT_DEBUG_WORDS words; written by probe builds only, see include/mulut.h)
 };
 
 struct PassArgs {

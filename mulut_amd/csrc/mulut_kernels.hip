@@ -2581,6 +2581,10 @@ hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode
 #include "mulut_tube2_asm_dbg2.inc"
 #elif defined(MULUT_VARIANT_t2dbg3)
 #include "mulut_tube2_asm_dbg3.inc"
+#elif defined(MULUT_VARIANT_t2dbg4)
+#include "mulut_tube2_asm_dbg4.inc"
+#elif defined(MULUT_VARIANT_t2dbg5)
+#include "mulut_tube2_asm_dbg5.inc"
 #else
 #include "mulut_tube2_asm.inc"
 #endif
@@ -2731,6 +2735,13 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
 
     int tile = next_tile(first);
     if (tile >= last) return;              // workgroup-uniform
+#if defined(MULUT_VARIANT_t2prof)   /* probe build: shader-clock ticks per phase, summed over all waves into the context's probe buffer */
+    const unsigned long long t_first = __builtin_amdgcn_s_memtime(), r_first = __builtin_amdgcn_s_memrealtime();
+    uint32_t t_prev = (uint32_t)t_first, t_ph0 = 0, t_ph1 = 0, t_ph2 = 0, t_ph3 = 0, t_ph4 = 0, t_ph5 = 0;      // wave-uniform (scalar registers)
+#define T2_STAMP(PH) do { const uint32_t t_now = (uint32_t)__builtin_amdgcn_s_memtime(); t_ph##PH += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define T2_STAMP(PH) do { } while (0)
+#endif
     uint32_t pix[PER4];
     fetch(tile, pix);
     // bands: slot = pattern id of the mode; patterns the mode list lacks are never read
@@ -2752,6 +2763,10 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
         asm volatile("" : "+v"(tid2));
         const int tx = tid2 % TW, ty = tid2 / TW;
         const int y = y0 + ty, x = x0 + tx;
+        T2_STAMP(0);       // tile decode, next tile's fetch issued
+#if defined(MULUT_VARIANT_t2x2)      /* timing-only: every site computed (and stored) twice per tile */
+        for (int rep = 0; rep < 2; ++rep)
+#endif
         if (y < a.oy1 && x < a.W) {
             // LDS byte address of the 5x5 window corner (y-2, x-2) of this site, channel 0
             uint32_t win = (uint32_t)(3 * kTubeBandBytes + (it & 1) * kTubeTileBytes + 2 * (ty * PW + tx + kTubeHaloX - kHalo));
@@ -2781,6 +2796,7 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
             }
             RotAcc<4> acc;
             acc.clear();
+            T2_STAMP(1);   // pipeline prologue: neighbours of pairs 0 and 1, index math, first rows requested
 #pragma clang loop unroll(disable)
             for (int c = 0; c < a.C; ++c, win += kT2Chan) {
                 const bool more = c + 1 < a.C;       // wave-uniform
@@ -2821,6 +2837,7 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                 dirty = dirty_n;
                 dirty_n = 0u;
             }
+            T2_STAMP(2);   // the channels: 12 passes + epilogue each
             if constexpr (OUT == kOutPackedRGBU4) {
                 const uint4 r = park[0], g = park[NT];
                 const uint32_t oR[4] = {r.x, r.y, r.z, r.w}, oG[4] = {g.x, g.y, g.z, g.w};
@@ -2840,10 +2857,25 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                 }
             }
         }
+        T2_STAMP(3);       // output stores, fix-up list
         if (nxt_tile < last) stash(nxt_tile, (it + 1) & 1, pix);
+        T2_STAMP(4);       // next tile's pixel codes into LDS (waits for its fetch)
+#if !defined(MULUT_VARIANT_t2x1)     /* t2x1 = timing-only: no barrier between tiles */
         __syncthreads();     // next tile published; everyone is done reading the current one
+#endif
+        T2_STAMP(5);       // barrier
         tile = nxt_tile;
     }
+#if defined(MULUT_VARIANT_t2prof)
+    if (a.dbg && (threadIdx.x & 63) == 0) {
+        atomicAdd(a.dbg + 0, (unsigned long long)t_ph0); atomicAdd(a.dbg + 1, (unsigned long long)t_ph1); atomicAdd(a.dbg + 2, (unsigned long long)t_ph2);
+        atomicAdd(a.dbg + 3, (unsigned long long)t_ph3); atomicAdd(a.dbg + 4, (unsigned long long)t_ph4); atomicAdd(a.dbg + 5, (unsigned long long)t_ph5);
+        atomicAdd(a.dbg + 6, __builtin_amdgcn_s_memtime() - t_first);          // wave lifetime in shader-clock ticks ...
+        atomicAdd(a.dbg + 7, __builtin_amdgcn_s_memrealtime() - r_first);      // ... and in 100 MHz ticks: their ratio is the in-kernel clock
+        atomicAdd(a.dbg + 8, 1ull);
+    }
+#endif
+#undef T2_STAMP
 }
 
 constexpr int kT2PatsSDY = 3 | (0 << 2) | (1 << 4) | (2 << 6);

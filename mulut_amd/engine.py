@@ -204,6 +204,14 @@ class MuLUTEngine:
             return {"samples_per_anchor": [], "items": 0, "fix_pixels": 0, "probe": []}
         return {"samples_per_anchor": v[:16], "items": v[16], "fix_pixels": v[17], "probe": v[18:]}
 
+    def debug_read(self, words=64, reset=True):
+        """The first `words` 64-bit words of the context's probe buffer (written by probe builds of the kernels only)."""
+        buf = (ctypes.c_uint64 * words)()
+        n = self._lib.mulut_debug_read(self._h, buf, words, 1 if reset else 0, self._stream())
+        if n < 0:
+            self._check(n)
+        return [int(buf[k]) for k in range(n)]
+
     def eval_y(self, gt_hwc, out_hwc, shave):
         """(PSNR, SSIM) on the Y channel of two device uint8 HWC RGB images, as sr/4_test_lut.py:313-315 scores a result
         (common/utils.py:42-101) -- computed on the device, only two doubles come back."""

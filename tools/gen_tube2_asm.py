@@ -11,8 +11,10 @@ refill the row's registers with the NEXT pass's row.  LDS returns in order, so t
 import os
 import sys
 
-DEBUG = int(os.environ.get("TUBE2_DEBUG", "0"))      # 1: s_nop 4 after every wait, 2: every wait drains (lgkmcnt(0)), 3: s_nop 4 at the end of every block
+DEBUG = int(os.environ.get("TUBE2_DEBUG", "0"))      # timing / debugging builds (MULUT_VARIANT_t2dbgN): 1: s_nop 4 after every wait, 2: every wait drains (lgkmcnt(0)),
+# 3: s_nop 4 at the end of every block, 4: no row reads (wrong results: VALU-only time), 5: no MACs (wrong results: LDS-only time)
 
+WAIT_GROUPS = [[int(c) for c in g] for g in os.environ.get("TUBE2_WAITS", "012,34").split(",")]
 ROW0 = 88          # v88..v127: rows 0..4, eight dwords each (LO plane x,y,z,w then HI plane x,y,z,w); tuples start on even registers
 WAVES_PER_EU = 6   # the kernel is built with amdgpu_waves_per_eu(6, 6): a hard cap of 512 / 6 -> 84 registers for the register
                    # allocator (it was seen to use v0..v80).  amdgpu_num_vgpr does not bind it, and asm clobbers alone only keep LONG-lived
@@ -128,14 +130,20 @@ def block(q, rev, nn, loads, addr_half, cur, nxt):
     if loads:
         o += addr_ops(addr_half, "base", "s")
     for j in range(5):
-        q.need(["%s%dl" % (cur, j), "%s%dh" % (cur, j)])
+        # rows are waited for in groups (every s_waitcnt is an instruction of the wave's issue budget): the reads were issued a
+        # whole pass ago, only the last ones can still be on their way
+        grp = [g for g in WAIT_GROUPS if g[0] == j]
+        if grp:
+            q.need(["%s%d%s" % (cur, r, h) for r in grp[0] for h in "lh"])
         if j == 0 and nn:
             q.issue(["n%d" % i for i in range(nn)])
             o += nb_loads(nn == 7)
-        o += mac8(j, rev)
+        if DEBUG != 5:
+            o += mac8(j, rev)
         if loads:
             q.issue(["%s%dl" % (nxt, j), "%s%dh" % (nxt, j)])
-            o += row_loads(j)
+            if DEBUG != 4:
+                o += row_loads(j)
     if nn:
         q.need(["n%d" % i for i in range(7)])
         o += unpack(nn == 7)
@@ -160,7 +168,7 @@ def main():
     out.append(cstr("TUBE2_ASM_LOAD_NB", nb_loads(False) + ["s_waitcnt lgkmcnt(0)"] + unpack(False)))
     p1 = addr_ops(0, "base", "s")
     for j in range(5):
-        p1 += row_loads(j)
+        p1 += row_loads(j) if DEBUG != 4 else []
     out.append(cstr("TUBE2_ASM_FIRST_ROWS", p1))
     # a pair = block A (first pass, rotation r: refills with the pair's second pass) + block B (second pass, rotation r + 2: fetches
     # and merges the neighbour codes of the pair after next, refills with the next pair's first pass).  B starts on the queue A
@@ -177,7 +185,7 @@ def main():
     block(ql, True, 0, False, 0, "B", "A")
     assert ql.q == [], ql.q
     out.append(cstr("TUBE2_ASM_B_LAST", ql.out))
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mulut_amd", "csrc", "mulut_tube2_asm%s.inc" % ("_dbg%d" % DEBUG if DEBUG else ""))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mulut_amd", "csrc", "mulut_tube2_asm%s.inc" % ("_dbg%s" % os.environ.get("TUBE2_TAG", DEBUG) if (DEBUG or os.environ.get("TUBE2_TAG")) else ""))
     with open(path, "w") as f:
         f.write("\n".join(out))
     print("wrote", path)
