@@ -2595,9 +2595,13 @@ struct T2Pair {
 };
 __host__ __device__ constexpr int t2_modes(int pats) { return pats & 3; }
 __host__ __device__ constexpr int t2_pat(int pats, int m) { return (pats >> (2 + 2 * m)) & 3; }
-constexpr int kTube2LdsBytes = kTubeLdsBytes + 2 * 16 * KB_TW * KB_TH;      // + the parked output rows of channels 0 and 1 (RGB path)
+constexpr int kT2W = 16, kT2H = 4;        // a wave's tile: 16 x 4 pixels, one site per lane (192 contiguous output bytes per HR row)
+constexpr int kT2PW = kT2W + 2 * kTubeHaloX, kT2PH = kT2H + 2 * kHalo, kT2Chan = 2 * kT2PH * kT2PW;
+constexpr int kT2WaveTileBytes = 3 * kT2Chan;
+// LDS: [ band s | band d | band y ][ 16 wave images of pixel codes ][ parked output rows of channels 0 and 1 (RGB path) ][ work counter ]
+constexpr int kTube2LdsBytes = 3 * kTubeBandBytes + 16 * kT2WaveTileBytes + 2 * 16 * KB_TW * KB_TH + 16;
 static_assert(kTube2LdsBytes <= 160 * 1024, "LDS budget");
-constexpr int kT2PW = KB_TW + 2 * kTubeHaloX, kT2PH = KB_TH + 2 * kHalo, kT2Chan = 2 * kT2PH * kT2PW;
+static_assert(KB_TW % kT2W == 0 && KB_TH % kT2H == 0 && (KB_TW / kT2W) * (KB_TH / kT2H) == 16 && KB_TW / kT2W == 4, "16 wave tiles per verdict tile, four across");
 // byte offset (from the window corner) of neighbour K of pattern PAT under rotation R; SIGN -1: rotation R + 2
 __host__ __device__ constexpr int t2_nb(int pat, int r, int k, int sign) {
     return 2 * ((2 + sign * rot_dy(r, kPatDi[pat][k], kPatDj[pat][k])) * kT2PW + 2 + sign * rot_dx(r, kPatDi[pat][k], kPatDj[pat][k]));
@@ -2663,13 +2667,19 @@ __device__ __forceinline__ void t2_block_b(uint32_t (&lo)[4], uint32_t (&hi)[4],
         asm volatile(TUBE2_ASM_B_N7 : T2_ACC_OPS(lo, hi), T2_TMP_OPS, T2_NBOUT_OPS, [ca] "=&v"(ca) : T2_W_OPS(cur), T2_ADDR_OPS(nxt), T2_IMM_OPS(NPAT), [win] "v"(win), T2_NB_OPS(TPAT, TR, TOFF) : TUBE2_CLOBBERS);
 }
 
+// Work decomposition: NO workgroup barrier after the bands are staged.  The phase stamps of the first version (one 64 x 16 tile per
+// workgroup and barrier) showed every wave parked at the tile barrier for 30 % of its life: the SIMD arbitrates oldest-first, so a
+// tile's waves finish far apart, and while the early ones wait the SIMD runs at the issue rate of one or two waves.  Here a WAVE owns
+// a 16 x 4 pixel tile (one site per lane) with a private 24 x 8 x C image of pixel codes in LDS; it draws its next tile from a
+// workgroup counter in LDS (a workgroup still owns an XCD-contiguous run of 64 x 16 verdict tiles = 16 wave tiles each), fetches it
+// while it computes the current one, and never waits for another wave.
 template <int OUT, int PATS>
 __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_eu(TUBE2_WAVES_PER_EU, TUBE2_WAVES_PER_EU))) stage_tube2_kernel(StageArgs a, BandArgs b) {
     constexpr int TW = KB_TW, TH = KB_TH, PW = kT2PW, PH = kT2PH, NT = TW * TH;
     constexpr int M = t2_modes(PATS), NP = 2 * M;
-    constexpr int DW = PW / 4, PER4 = (3 * PH * DW + NT - 1) / NT;
-    static_assert(((2 * 3 * PH * PW + 15) / 16) * 16 == kTubeTileBytes, "tile buffer size");
+    constexpr int DW = PW / 4, PER4 = (3 * PH * DW + 63) / 64;         // aligned dwords per image row / per lane
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *s_next = (uint32_t *)(smem + kTube2LdsBytes - 16);       // the workgroup's next work item
 
     const int ntiles = a.N * a.tiles_x * a.tiles_y;
     const int G = gridDim.x;
@@ -2678,41 +2688,62 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
     const int first = by_xcd ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int last = by_xcd ? imin(((int)(blockIdx.x & 7) + 1) * per, ntiles) : ntiles;
     const int step = by_xcd ? (G >> 3) : G;
-    auto next_tile = [&](int t) {
-        if (a.verdict_take >= 0)
-            while (t < last && (int)a.verdict[t] != a.verdict_take) t += step;
-        return t;
-    };
-    const int total = a.C * PH * PW;
+    if (first >= last) return;              // workgroup-uniform
     const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
     const bool dw_ok = a.in.sX == 1 && ((a.W | a.in.sY | a.in.sC) & 3) == 0 && (a.in.sN & 3) == 0 && (((uintptr_t)a.in.p) & 3) == 0;
-    auto fetch = [&](int tile, uint32_t (&v)[PER4]) {
-        if (!dw_ok) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint8_t *img = smem + 3 * kTubeBandBytes + wave * kT2WaveTileBytes;      // this wave's image of pixel codes
+
+    // work item j of the workgroup = wave tile j & 15 of its (j >> 4)-th verdict tile; -1 = none left.  Lane-uniform.
+    auto grab = [&]() {
+        for (;;) {
+            uint32_t j = 0;
+            if ((threadIdx.x & 63) == 0) j = atomicAdd(s_next, 1u);
+            j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+            const long long tile = (long long)first + (long long)(j >> 4) * step;
+            if (tile >= last) return -1;
+            if (a.verdict_take >= 0 && (int)a.verdict[tile] != a.verdict_take) continue;
+            int n, ty0, tx0;
+            decode_tile(a, (int)tile, n, ty0, tx0, TW, TH);
+            if (tx0 + kT2W * (int)(j & 3u) >= a.W || ty0 + kT2H * (int)((j >> 2) & 3u) >= a.oy1) continue;
+            return (int)j;
+        }
+    };
+    auto origin = [&](int j, int &n, int &y0, int &x0) {
+        decode_tile(a, first + (j >> 4) * step, n, y0, x0, TW, TH);
+        x0 += kT2W * (j & 3);
+        y0 += kT2H * ((j >> 2) & 3);
+    };
+    // Planar input whose rows start on dword boundaries (the pipeline's intermediate images): a wave tile is fetched as aligned
+    // dwords, in flight while the previous tile is computed.  Any other input takes the byte path at stash time.
+    auto fetch = [&](int j, uint32_t (&v)[PER4]) {
+        if (!dw_ok || j < 0) return;
         int n, y0, x0;
-        decode_tile(a, tile, n, y0, x0, TW, TH);
-        int tid = (int)threadIdx.x;       // opaque: no per-thread term of this may stay live across a tile's computation
-        asm volatile("" : "+v"(tid));
+        origin(j, n, y0, x0);
+        int lane = (int)(threadIdx.x & 63);       // opaque: no per-lane term of this may stay live across a tile's computation
+        asm volatile("" : "+v"(lane));
 #pragma unroll
         for (int k = 0; k < PER4; ++k) {
-            const int i = tid + k * NT;
+            const int i = lane + 64 * k;
             const int q = i % DW, py = (i / DW) % PH, c = imin(i / (DW * PH), a.C - 1);
             const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
             const int gx = imin(imax(x0 - kTubeHaloX + 4 * q, 0), a.W - 4);
             v[k] = *(const uint32_t *)view_addr(a.in, n, c, gy, gx);
         }
     };
-    auto stash = [&](int tile, int buf, const uint32_t (&v)[PER4]) {
+    auto stash = [&](int j, const uint32_t (&v)[PER4]) {
+        if (j < 0) return;
         int n, y0, x0;
-        decode_tile(a, tile, n, y0, x0, TW, TH);
-        uint8_t *dst = smem + 3 * kTubeBandBytes + buf * kTubeTileBytes;
+        origin(j, n, y0, x0);
+        int lane = (int)(threadIdx.x & 63);
+        asm volatile("" : "+v"(lane));
         if (dw_ok) {
-            int tid = (int)threadIdx.x;
-            asm volatile("" : "+v"(tid));
 #pragma unroll
             for (int k = 0; k < PER4; ++k) {
-                const int i = tid + k * NT;
+                const int i = lane + 64 * k;
                 if (i < a.C * PH * DW) {
                     const int gx = x0 - kTubeHaloX + 4 * (i % DW);
+                    // bytes (b0,b1) / (b2,b3) into 16-bit lanes; a dword clamped at an image edge replicates the edge byte
                     const uint32_t sel_lo = gx < 0 ? 0x0C000C00u : gx > a.W - 4 ? 0x0C030C03u : 0x0C010C00u;
                     const uint32_t sel_hi = gx < 0 ? 0x0C000C00u : gx > a.W - 4 ? 0x0C030C03u : 0x0C030C02u;
                     const uint32_t lo = __builtin_amdgcn_perm(0u, v[k], sel_lo), hi = __builtin_amdgcn_perm(0u, v[k], sel_hi);
@@ -2720,21 +2751,19 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                     uint2 c2;
                     c2.x = pk_mad(lo, pk_dup(0x1000u), pk_shr4(lo));
                     c2.y = pk_mad(hi, pk_dup(0x1000u), pk_shr4(hi));
-                    *(uint2 *)(dst + 8 * i) = c2;
+                    *(uint2 *)(img + 8 * i) = c2;
                 }
             }
         } else {
-            for (int i = threadIdx.x; i < total; i += NT) {
+            for (int i = lane; i < a.C * PH * PW; i += 64) {
                 const int px = i % PW, py = (i / PW) % PH, c = i / (PW * PH);
                 const int gy = imin(imax(y0 + py - kHalo, ylo), yhi);
                 const int gx = imin(imax(x0 + px - kTubeHaloX, 0), a.W - 1);
-                ((uint16_t *)dst)[i] = (uint16_t)pixel_code1(*view_addr(a.in, n, c, gy, gx));
+                ((uint16_t *)img)[i] = (uint16_t)pixel_code1(*view_addr(a.in, n, c, gy, gx));
             }
         }
     };
 
-    int tile = next_tile(first);
-    if (tile >= last) return;              // workgroup-uniform
 #if defined(MULUT_VARIANT_t2prof)   /* probe build: shader-clock ticks per phase, summed over all waves into the context's probe buffer */
     const unsigned long long t_first = __builtin_amdgcn_s_memtime(), r_first = __builtin_amdgcn_s_memrealtime();
     uint32_t t_prev = (uint32_t)t_first, t_ph0 = 0, t_ph1 = 0, t_ph2 = 0, t_ph3 = 0, t_ph4 = 0, t_ph5 = 0;      // wave-uniform (scalar registers)
@@ -2742,8 +2771,6 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
 #else
 #define T2_STAMP(PH) do { } while (0)
 #endif
-    uint32_t pix[PER4];
-    fetch(tile, pix);
     // bands: slot = pattern id of the mode; patterns the mode list lacks are never read
     static_for<0, M>([&](auto MI) {
         constexpr int pat = t2_pat(PATS, MI);
@@ -2751,28 +2778,30 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
         uint4 *dst = (uint4 *)(smem + pat * kTubeBandBytes);
         for (int i = threadIdx.x; i < kTubeBandBytes / 16; i += NT) dst[i] = src[i];
     });
-    stash(tile, 0, pix);
-    __syncthreads();
+    if (threadIdx.x == 0) *s_next = 0u;
+    __syncthreads();          // the only barrier of the kernel
+    T2_STAMP(5);
 
-    for (int it = 0; tile < last; ++it) {
-        const int nxt_tile = next_tile(tile + step);
-        if (nxt_tile < last) fetch(nxt_tile, pix);
+    uint32_t pix[PER4];
+    int item = grab();
+    fetch(item, pix);
+    stash(item, pix);
+    while (item >= 0) {
+        const int nxt_item = grab();
+        fetch(nxt_item, pix);
         int n, y0, x0;
-        decode_tile(a, tile, n, y0, x0, TW, TH);
-        int tid2 = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid2));
-        const int tx = tid2 % TW, ty = tid2 / TW;
-        const int y = y0 + ty, x = x0 + tx;
-        T2_STAMP(0);       // tile decode, next tile's fetch issued
-#if defined(MULUT_VARIANT_t2x2)      /* timing-only: every site computed (and stored) twice per tile */
-        for (int rep = 0; rep < 2; ++rep)
-#endif
+        origin(item, n, y0, x0);
+        int lane2 = (int)(threadIdx.x & 63);
+        asm volatile("" : "+v"(lane2));
+        const int lx = lane2 % kT2W, ly = lane2 / kT2W;
+        const int y = y0 + ly, x = x0 + lx;
+        T2_STAMP(0);       // work item drawn, next tile's fetch issued
         if (y < a.oy1 && x < a.W) {
             // LDS byte address of the 5x5 window corner (y-2, x-2) of this site, channel 0
-            uint32_t win = (uint32_t)(3 * kTubeBandBytes + (it & 1) * kTubeTileBytes + 2 * (ty * PW + tx + kTubeHaloX - kHalo));
+            uint32_t win = (uint32_t)(3 * kTubeBandBytes + wave * kT2WaveTileBytes + 2 * (ly * PW + lx + kTubeHaloX - kHalo));
             // finished channels wait in LDS for the RGB interleave (a uint4 per thread and channel): registers are what the
             // pipelined loop below is short of
-            uint4 *park = (uint4 *)(smem + kTubeLdsBytes) + threadIdx.x;
+            uint4 *park = (uint4 *)(smem + 3 * kTubeBandBytes + 16 * kT2WaveTileBytes) + threadIdx.x;
             uint32_t dmask = 0u, dirty = 0u, dirty_n = 0u;
             uint32_t o[4] = {0u, 0u, 0u, 0u};
             uint32_t pb, pc, pd, ca;
@@ -2829,7 +2858,6 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                     tube_finish_rows(a, acc, o);
                     if (c < 2) park[c * NT] = make_uint4(o[0], o[1], o[2], o[3]);
                 } else {
-                    uint32_t o[4];
                     finish_channel<4, OUT>(a, acc, n, c, y, x, o);
                 }
                 acc.clear();
@@ -2843,6 +2871,7 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                 const uint32_t oR[4] = {r.x, r.y, r.z, r.w}, oG[4] = {g.x, g.y, g.z, g.w};
                 store_rgb<4>(a, n, y, x, oR, oG, o);
             }
+            // dirty samples (pixel, channel) go on the fix-up list: one atomic per wave and channel (rare), compacted by lane rank
             if (__ballot(dmask != 0u) != 0ull) {
                 const uint32_t pixel_id = (uint32_t)((n * a.H + y) * a.W + x);
                 for (int c = 0; c < a.C; ++c) {
@@ -2858,13 +2887,9 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
             }
         }
         T2_STAMP(3);       // output stores, fix-up list
-        if (nxt_tile < last) stash(nxt_tile, (it + 1) & 1, pix);
+        stash(nxt_item, pix);      // the wave's image is its own: every read of the current tile has returned (the pipeline drained)
         T2_STAMP(4);       // next tile's pixel codes into LDS (waits for its fetch)
-#if !defined(MULUT_VARIANT_t2x1)     /* t2x1 = timing-only: no barrier between tiles */
-        __syncthreads();     // next tile published; everyone is done reading the current one
-#endif
-        T2_STAMP(5);       // barrier
-        tile = nxt_tile;
+        item = nxt_item;
     }
 #if defined(MULUT_VARIANT_t2prof)
     if (a.dbg && (threadIdx.x & 63) == 0) {
