@@ -85,7 +85,7 @@ def cpu_baseline_host(luts, frame_u8, crop):
     ref_c = c_oracle.pipeline(luts, STAGES, MODES, SCALE, win)
     dtc = time.perf_counter() - t0
     H, W = frame_u8.shape[:2]
-    T, halo = 128, 2 * STAGES
+    T, halo = 64, 2 * STAGES      # 17 x 30 = 510 tiles of a 1080p frame: every host core gets work
     jobs = []
     for r0 in range(0, H, T):
         for c0 in range(0, W, T):
@@ -103,7 +103,7 @@ def cpu_baseline_host(luts, frame_u8, crop):
     rec = {
         "value": round(H * W * SCALE * SCALE / dtp / 1e6, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
         "sample": "oracle/np_port.py (NumPy port of sr/4_test_lut.py: float, 16 corner gathers + 24 masked cases per pass) on "
-                  "frame 0 (LR %dx%dx3), multiprocessing Pool over %d tiles of 128x128 (+%d-pixel halo) on %d processes, %.1f s"
+                  "frame 0 (LR %dx%dx3), multiprocessing Pool over %d tiles of 64x64 (+%d-pixel halo) on %d processes, %.1f s"
                   % (H, W, len(jobs), halo, cores, dtp),
         "single_core_value": round(crop * crop * SCALE * SCALE / dt1 / 1e6, 5),
         "single_core_sample": "the same port, one process, top-left %dx%dx3 window of frame 0, %.1f s" % (crop, crop, dt1),
@@ -318,7 +318,7 @@ def main():
     # config 3: LR 2160x3840 frames.  N = 1: whole frames on the one GPU.  N > 1: every frame cut into one strip per rank
     # (+halo), cascade per strip, HR strips sent point to point (RCCL) into the frame on rank 0; the gather of batch k
     # overlaps the compute of batch k + 1.  The headline record is complete before this leg starts and cannot be lost to
-    # it: an exception is recorded, and a watchdog prints the record without the leg (and ends every rank) if the exchange
+    # it: an exception is recorded, and a watchdog prints the record without the leg and ends every rank with exit code 3 if the exchange
     # has not come back in time.
     strips = None
     if not args.skip_strips:
@@ -333,7 +333,7 @@ def main():
                 if rank == 0:
                     rec["config"]["strips_gather"] = {"error": "no result within %d s; headline printed without it" % args.strips_timeout}
                     print(json.dumps(rec), flush=True)
-            os._exit(0)
+            os._exit(3)      # a hung exchange is a failure: the record is out, the run must not read as green
         timer = threading.Timer(args.strips_timeout, give_up)
         timer.daemon = True
         timer.start()
@@ -368,49 +368,65 @@ def config3(args, eng, world, rank, dist_on, backend, timed):
         el = timed(lambda: eng.pipeline(x, out=out), steps)
         return {"workload": "config 3 on one GPU: %d x LR %dx%dx3 whole frames per step" % (Fs, Hs, Ws), "n_gpus": 1,
                 "value": round(Fs * Hs * SCALE * Ws * SCALE * steps / el / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(el / steps * 1e3, 3)}
-    lr = torch.from_numpy(frames)
-    outs = [torch.empty((Fs, Hs * SCALE, Ws * SCALE, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None for _ in range(2)]
-    pend = [None, None]
     via_host = backend != "nccl"
+    import time as _t
 
     def compute(band, r0, y0, y1, hh):
         return eng.pipeline_rows(band, r0, y0, y1, hh)
 
-    k = [0]
+    def leg(mode, nfr):
+        """nfr frames per step; mode "root": every HR strip goes to rank 0; "rotate": frame n is assembled on rank n % world."""
+        lr = torch.from_numpy(make_batch(args.dist, nfr, Hs, Ws, seed=0) if nfr != Fs else frames)
+        if mode == "root":
+            held = nfr if rank == 0 else 0
+        else:
+            held = len([n for n in range(nfr) if n % world == rank])
+        outs = [torch.empty((held, Hs * SCALE, Ws * SCALE, 3), dtype=torch.uint8, device="cuda") if held else None for _ in range(2)]
+        pend = [None, None]
+        k = [0]
 
-    def step():
-        b = k[0] & 1
-        if pend[b] is not None:
-            pend[b].wait()                       # the gather issued two steps ago has landed: its buffer is free
-        pend[b] = sr_strips(lr, compute, SCALE, eng.halo, dst=0, out=outs[b], device="cuda", via_host=via_host, wait=False)
-        k[0] += 1
-
-    def drain():
-        for b in (0, 1):
+        def step():
+            b = k[0] & 1
             if pend[b] is not None:
-                pend[b].wait()
-                pend[b] = None
-    step(); drain()
-    import time as _t
-    if dist_on:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = _t.perf_counter()
-    for _ in range(steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if dist_on:
-        torch.distributed.barrier()
-    el = _t.perf_counter() - t0
-    t = torch.tensor([el], dtype=torch.float64, device="cuda")
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    el = float(t.item())
-    return {"workload": "config 3: %d x LR %dx%dx3 frames per step, each cut into %d strips (+%d-row halo); HR strips sent point to "
-                        "point into the frames on rank 0 (%s), the exchange of step k overlapping the compute of step k+1"
-                        % (Fs, Hs, Ws, world, eng.halo, "RCCL" if backend == "nccl" else backend + " via host memory"),
-            "n_gpus": world, "scaling": "strong", "value": round(Fs * Hs * SCALE * Ws * SCALE * steps / el / 1e6, 2), "unit": "Mpix/s",
-            "ms_per_step": round(el / steps * 1e3, 3), "gathered_bytes_per_step": Fs * Hs * SCALE * Ws * SCALE * 3 * (world - 1) // world}
+                pend[b].wait()                       # the exchange issued two steps ago has landed: its buffer is free
+            pend[b] = sr_strips(lr, compute, SCALE, eng.halo, dst=0 if mode == "root" else "rotate", out=outs[b], device="cuda", via_host=via_host, wait=False)
+            k[0] += 1
+
+        def drain():
+            for b in (0, 1):
+                if pend[b] is not None:
+                    pend[b].wait()
+                    pend[b] = None
+        step(); drain()
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for _ in range(steps):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        if dist_on:
+            torch.distributed.barrier()
+        el = _t.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+        frame_bytes = Hs * SCALE * Ws * SCALE * 3
+        del outs
+        torch.cuda.empty_cache()
+        return {"frames_per_step": nfr, "value": round(nfr * Hs * SCALE * Ws * SCALE * steps / el / 1e6, 2), "unit": "Mpix/s",
+                "ms_per_step": round(el / steps * 1e3, 3), "exchanged_bytes_per_step": nfr * frame_bytes * (world - 1) // world,
+                "max_bytes_into_one_rank_per_step": (nfr if mode == "root" else -(-nfr // world)) * frame_bytes * (world - 1) // world}
+    rot_frames = world * max(1, Fs // world)
+    rec = {"workload": "config 3: LR %dx%dx3 frames, each cut into %d strips (+%d-row halo) computed on %d GPUs; the HR strips travel point to point "
+                       "(%s) straight into their rows, the exchange of step k overlapping the compute of step k+1"
+                       % (Hs, Ws, world, eng.halo, world, "RCCL" if backend == "nccl" else backend + " via host memory"),
+           "n_gpus": world, "scaling": "strong", "ranks_in_group": torch.distributed.get_world_size()}
+    rec["single_root"] = leg("root", Fs)
+    rec["rotate"] = leg("rotate", rot_frames)
+    rec["value"], rec["unit"], rec["ms_per_step"] = rec["rotate"]["value"], "Mpix/s", rec["rotate"]["ms_per_step"]      # the mode that scales
+    return rec
 
 
 def config4(args, world, rank, local, timed):

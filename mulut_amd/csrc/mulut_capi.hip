@@ -57,7 +57,7 @@ struct mulut_ctx {
     uint4 *det_blocks = nullptr;
     size_t det_items_cap = 0, det_ids_cap = 0, det_blocks_cap = 0, det_tiles_cap = 0;
     bool k1_valid = false;         // ctx->tlist holds the marks of the first-stage launch that produced the next stage's input ...
-    int k1_N = 0, k1_W = 0, k1_tiles_x = 0, k1_tiles_y = 0, k1_oy0 = 0;   // ... of this shape ...
+    int k1_N = 0, k1_W = 0, k1_H = 0, k1_tiles_x = 0, k1_tiles_y = 0, k1_oy0 = 0, k1_oy1 = 0;   // ... of this shape ...
     const uint8_t *k1_out = nullptr;                                      // ... written to this buffer
     int stat_from_k1 = 1;          // tuning "stat_from_first_stage": the final stage's statistic looks only at tiles the first stage marked
     int tube2 = 1;                 // tuning "tube_pipelined": 1 = stage_tube2_kernel (hand-scheduled LDS reads) where the mode list has one, 0 = stage_tube_kernel
@@ -470,7 +470,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.tiles_y = (oy1 - oy0 + th - 1) / th;
     if (u == 1 && last) a.use_fma = 0;     // (a final stage with 1-byte rows -- scale 1 -- takes the integer epilogue)
     // marks of the first-stage launch that produced this stage's input (same buffer, same shape); consumed here, never kept
-    const bool k1_marks = ctx->k1_valid && ctx->k1_out == in.p && ctx->k1_N == N && ctx->k1_W == W && ctx->k1_oy0 <= oy0;
+    const bool k1_marks = ctx->k1_valid && ctx->k1_out == in.p && ctx->k1_N == N && ctx->k1_W == W && ctx->k1_H == H && ctx->k1_oy0 <= oy0 &&
+                          oy1 <= ctx->k1_oy1;      // the marks cover exactly the rows that launch wrote: never index past its tile grid
     ctx->k1_valid = false;
     if (u == 1) {
         const bool tube1 = (ctx->first_kernel == 0 || ctx->first_kernel == 3) && ctx->n_modes <= 3 &&
@@ -499,7 +500,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         if (route) HIP_TRY(ctx, launch_stage_u1w_list(a, ctx->num_cus, st));
         HIP_TRY(ctx, launch_stage_u1_fix(a, ctx->num_cus, st));
         ctx->k1_valid = route;
-        ctx->k1_N = N; ctx->k1_W = W; ctx->k1_tiles_x = a.tiles_x; ctx->k1_tiles_y = a.tiles_y; ctx->k1_oy0 = oy0;
+        ctx->k1_N = N; ctx->k1_W = W; ctx->k1_tiles_x = a.tiles_x; ctx->k1_tiles_y = a.tiles_y; ctx->k1_oy0 = oy0; ctx->k1_oy1 = oy1; ctx->k1_H = H;
         ctx->k1_out = out.p;
         return MULUT_OK;
     }

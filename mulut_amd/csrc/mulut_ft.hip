@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
             s_g[threadIdx.x][eo] = g[eo];
         });
     }
+    if constexpr (U == 1) __syncthreads();      // the band must be zero before any wave adds into it (no other barrier precedes the adds)
     for (int m = 0; m < a.M; ++m) {
         const float *tab = a.w[m];
         float *gtab = a.gw[m];

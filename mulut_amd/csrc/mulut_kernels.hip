@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_tile = smem + 3 * BB;
     uint32_t *s_cnt = (uint32_t *)(smem + 3 * BB + kU1tTileBytes);     // [0] detailed groups, [1] groups looked at
-    if (lds_addr_of(smem) != 0u) return;      // the band reads assume the dynamic LDS block starts at address 0 (no static LDS here)
+    if (lds_addr_of(smem) != 0u) __builtin_trap();      // the band reads assume the dynamic LDS block starts at address 0 (no static LDS here): fail loudly, never skip the work
 
     for (int m = 0; m < a.M; ++m) {
         const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
@@ -2680,6 +2680,7 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
     constexpr int DW = PW / 4, PER4 = (3 * PH * DW + 63) / 64;         // aligned dwords per image row / per lane
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *s_next = (uint32_t *)(smem + kTube2LdsBytes - 16);       // the workgroup's next work item
+    if (lds_addr_of(smem) != 0u) __builtin_trap();      // every LDS address below is absolute: the dynamic block must start at 0 (no static LDS here)
 
     const int ntiles = a.N * a.tiles_x * a.tiles_y;
     const int G = gridDim.x;
@@ -3478,7 +3479,7 @@ __device__ __forceinline__ void slab_mode(const StageArgs &a, int pat, uint32_t 
 
 __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, DetailArgs d) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    if (lds_addr_of(smem) != 0u) return;      // the row reads assume the slab pair starts at LDS address 0 (no static LDS here)
+    if (lds_addr_of(smem) != 0u) __builtin_trap();      // the row reads assume the slab pair starts at LDS address 0 (no static LDS here): fail loudly, never leave blocks unwritten
     const uint32_t nitems = d.ctl[kDetItems];
 #if defined(MULUT_VARIANT_slabclk)
     unsigned long long clk[4] = {0, 0, 0, 0}, clk_last = __builtin_amdgcn_s_memtime();

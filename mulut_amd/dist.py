@@ -13,6 +13,9 @@ Two shardings are offered:
   straight into its rows of ONE preallocated output -- strips may differ by a row, nothing is padded,
   concatenated or copied twice.  The input is sliced before it goes to the device: a rank uploads only its
   band.  ``wait=False`` returns the pending requests, so the next frame's compute overlaps this gather.
+  Who receives is a choice: one root (its ingress -- 7 xGMI links -- bounds the exchange: fine for one frame, ~1.7x at
+  most on 8 GPUs for a stream of them), every rank, or -- for batches -- ``dst="rotate"``: frame n is assembled on rank
+  n % world, an all-to-all in which every link carries 1/world^2 of the batch; ``dst="none"`` leaves the strips sharded.
 
 ``compute`` callables keep this module free of any engine dependency, so the CPU (gloo) tests can drive
 the same bookkeeping with a CPU test double.
@@ -40,19 +43,25 @@ def strip_band(height, world, rank, halo):
 
 
 class PendingGather:
-    """Handle of an asynchronous strip gather: ``wait()`` returns the assembled tensor (or None off-root)."""
+    """Handle of an asynchronous strip exchange: ``wait()`` returns the assembled tensor (None on a rank that receives
+    nothing).  ``frames`` lists the batch indices of the frames held in ``out`` (all of them, except in rotate mode)."""
 
-    def __init__(self, out, reqs, stage=None, stage_dst=None):
-        self.out, self._reqs, self._stage, self._stage_dst = out, reqs, stage, stage_dst
+    def __init__(self, out, reqs, copies=(), frames=None):
+        self.out, self._reqs, self._copies, self.frames = out, reqs, list(copies), frames
 
     def wait(self):
         for r in self._reqs:
             r.wait()
         self._reqs = []
-        if self._stage is not None:                 # host-staged receive (gloo rehearsal): back to the device
-            self._stage_dst.copy_(self._stage, non_blocking=False)
-            self._stage = None
+        for dst_view, src_view in self._copies:      # host-staged receives (gloo rehearsal): back to the device
+            dst_view.copy_(src_view)
+        self._copies = []
         return self.out
+
+
+def rotate_owner(frame, world):
+    """Rank that assembles `frame` of a batch in rotate mode."""
+    return frame % world
 
 
 def sr_strips(lr, compute, scale, halo, group=None, dst=0, out=None, device=None, via_host=False, wait=True):
@@ -62,11 +71,18 @@ def sr_strips(lr, compute, scale, halo, group=None, dst=0, out=None, device=None
               1/scale^2 of the output): only this rank's band (strip + halo) is sliced out and sent to `device`
     compute : callable(band, band_row0, y0, y1, H) -> uint8 tensor with the output rows of LR rows
               [y0,y1) (``MuLUTEngine.pipeline_rows`` on the GPU)
-    dst     : rank that receives the assembled frame; None = every rank
-    out     : optional preallocated [.., H*scale, W*scale, C] tensor on the receiving rank(s)
+    dst     : who ends up with whole frames --
+              an int   : that rank receives every frame (a single root: its ingress bounds the exchange);
+              None     : every rank receives every frame (all-gather);
+              "rotate" : batched input only: frame n is assembled on rank n % world -- an all-to-all of HR strips in which
+                         every rank receives (world-1)/world of the frames it owns and every link carries 1/world^2 of the
+                         batch: the mode that scales (DESIGN.md section 7);
+              "none"   : no exchange at all: the strips stay where they were computed (returns this rank's rows).
+    out     : optional preallocated result on the receiving rank(s): [.., H*scale, W*scale, C]; in rotate mode
+              [frames this rank owns, H*scale, W*scale, C]
     via_host: exchange through host memory (gloo rehearsals with device tensors; RCCL moves device memory directly)
-    wait    : False -> return a PendingGather at once (overlap the exchange with the next frame's compute)
-    returns the full [.., H*scale, W*scale, C] tensor on `dst` (or everywhere), else None.
+    wait    : False -> return a PendingGather at once (overlap the exchange with the next batch's compute)
+    returns the assembled tensor (or the PendingGather), None on a rank that receives nothing.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -74,58 +90,68 @@ def sr_strips(lr, compute, scale, halo, group=None, dst=0, out=None, device=None
     H = lr.shape[1] if batched else lr.shape[0]
     if H < world:
         raise ValueError("fewer image rows than ranks")
+    if dst == "rotate" and not batched:
+        raise ValueError("rotate mode needs a batch of frames [N,H,W,C]")
     r0, r1, y0, y1 = strip_band(H, world, rank, halo)
     band = (lr[:, r0:r1] if batched else lr[r0:r1]).contiguous()
     if device is not None and band.device != torch.device(device):
         band = band.to(device, non_blocking=True)
     mine = compute(band, r0, y0, y1, H)
+    nframes = mine.shape[0] if batched else 1
+    if dst == "none":
+        return mine if wait else PendingGather(mine, [], frames=list(range(nframes)))
+    # frames this rank assembles, and who assembles frame n
+    if dst == "rotate":
+        owners = [[rotate_owner(n, world)] for n in range(nframes)]
+    elif dst is None:
+        owners = [list(range(world))] * nframes
+    else:
+        owners = [[int(dst)]] * nframes
+    held = [n for n in range(nframes) if rank in owners[n]]
     if world == 1:
-        return mine if wait else PendingGather(mine, [])
+        if out is not None:
+            out.copy_(mine)
+            mine = out
+        return mine if wait else PendingGather(mine, [], frames=held)
     bounds = strip_bounds(H, world)
-    receiver = dst is None or rank == dst
     row_dim = 1 if batched else 0
-    if receiver:
+    if held:
         shape = list(mine.shape)
         shape[row_dim] = H * scale
+        if dst == "rotate":
+            shape[0] = len(held)
         if out is None:
             out = torch.empty(shape, dtype=mine.dtype, device=mine.device)
         elif list(out.shape) != shape:
             raise ValueError("out has shape %s, expected %s" % (tuple(out.shape), tuple(shape)))
-        out.narrow(row_dim, y0 * scale, (y1 - y0) * scale).copy_(mine)        # own strip: one device copy
-    # every frame of every strip is one contiguous block of rows of the output: point-to-point straight into place
-    frames = mine.shape[0] if batched else 1
+    else:
+        out = None
+    slot = {n: k for k, n in enumerate(held)} if dst == "rotate" else {n: n for n in held}
+
+    def frame_view(t, n):      # frame n of a result tensor (the whole tensor when the input was one image)
+        return t[slot[n]] if batched else t
+
+    # every strip of every frame is one contiguous block of rows of its destination: point-to-point straight into place
     send_buf = mine.cpu() if via_host else mine
-    stage = torch.empty(out.shape, dtype=out.dtype, device="cpu") if (via_host and receiver) else None
+    stage = torch.empty(out.shape, dtype=out.dtype, device="cpu") if (via_host and out is not None) else None
     recv_into = stage if stage is not None else out
-    ops = []
-    peers = range(world) if dst is None else [dst]
-    for p in peers:
-        if p == rank:
-            continue
-        for n in range(frames):
-            ops.append(dist.P2POp(dist.isend, send_buf[n] if batched else send_buf, p, group))
-    if receiver:
+    ops, copies = [], []
+    for n in range(nframes):
+        for p in owners[n]:
+            if p != rank:
+                ops.append(dist.P2POp(dist.isend, send_buf[n] if batched else send_buf, p, group))
+    for n in held:
+        frame_view(out, n).narrow(0, y0 * scale, (y1 - y0) * scale).copy_(mine[n] if batched else mine)      # own strip: one device copy
         for src in range(world):
             if src == rank:
                 continue
             a, b = bounds[src]
-            for n in range(frames):
-                view = (recv_into[n] if batched else recv_into).narrow(0, a * scale, (b - a) * scale)
-                ops.append(dist.P2POp(dist.irecv, view, src, group))
+            view = frame_view(recv_into, n).narrow(0, a * scale, (b - a) * scale)
+            ops.append(dist.P2POp(dist.irecv, view, src, group))
+            if stage is not None:      # rows received on the host go to the device at wait()
+                copies.append((frame_view(out, n).narrow(0, a * scale, (b - a) * scale), view))
     reqs = dist.batch_isend_irecv(ops) if ops else []
-    if stage is not None:
-        # rows received on the host go to the device at wait(); this rank's own rows are already there
-        class _Back:
-            def __init__(self, o, st, bnds, me):
-                self.o, self.st, self.b, self.me = o, st, bnds, me
-
-            def copy_(self, _src, non_blocking=False):
-                for src, (a, b) in enumerate(self.b):
-                    if src != self.me:
-                        self.o.narrow(row_dim, a * scale, (b - a) * scale).copy_(self.st.narrow(row_dim, a * scale, (b - a) * scale))
-        pending = PendingGather(out, reqs, stage, _Back(out, stage, bounds, rank))
-    else:
-        pending = PendingGather(out if receiver else None, reqs)
+    pending = PendingGather(out, reqs, copies, held)
     if not wait:
         return pending
     return pending.wait()

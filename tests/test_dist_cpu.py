@@ -44,7 +44,20 @@ def _worker(rank, world, port, dst, shape, q):
     try:
         luts = _luts()
         img = torch.from_numpy(np.random.default_rng(7).integers(0, 256, shape, dtype=np.uint8))
-        if img.dim() == 4:
+        if dst == "rotate":
+            # batched, frame n assembled on rank n % world, asynchronous handle; preallocated output on rank 0 only
+            owned = [n for n in range(shape[0]) if n % world == rank]
+            pre = torch.full((len(owned), shape[1] * SCALE, shape[2] * SCALE, shape[3]), 9, dtype=torch.uint8) if (rank == 0 and owned) else None
+            pend = sr_strips(img, _oracle_rows(luts), SCALE, HALO, dst="rotate", out=pre, wait=False)
+            out = pend.wait()
+            assert pend.frames == owned and ((out is pre) if pre is not None else True) and ((out is None) == (not owned))
+            want = [c_oracle.pipeline(luts, STAGES, MODES, SCALE, img.numpy()[n]) for n in owned]
+            q.put((rank, all(np.array_equal(out[k].numpy(), w) for k, w in enumerate(want)), None if out is None else tuple(out.shape)))
+            # sharded mode: nothing is exchanged, every rank keeps its rows
+            rows = sr_strips(img, _oracle_rows(luts), SCALE, HALO, dst="none")
+            a, b = strip_bounds(shape[1], world)[rank]
+            assert tuple(rows.shape) == (shape[0], (b - a) * SCALE, shape[2] * SCALE, shape[3])
+        elif img.dim() == 4:
             # batched case: preallocated output + asynchronous handle (what bench.py's config-3 leg does)
             shape_out = (shape[0], shape[1] * SCALE, shape[2] * SCALE, shape[3])
             pre = torch.full(shape_out, 7, dtype=torch.uint8) if (dst is None or rank == dst) else None
@@ -53,7 +66,9 @@ def _worker(rank, world, port, dst, shape, q):
             assert (out is pre) if pre is not None else (out is None)
         else:
             out = sr_strips(img, _oracle_rows(luts), SCALE, HALO, dst=dst)
-        if dst is None or rank == dst:
+        if dst == "rotate":
+            pass
+        elif dst is None or rank == dst:
             arr = img.numpy()
             want = np.stack([c_oracle.pipeline(luts, STAGES, MODES, SCALE, a) for a in (arr if arr.ndim == 4 else arr[None])])
             want = want if arr.ndim == 4 else want[0]
@@ -74,7 +89,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,dst,shape", [(2, 0, (37, 29, 3)), (2, None, (2, 23, 17, 3)), (3, 1, (31, 16, 1))])
+@pytest.mark.parametrize("world,dst,shape", [(2, 0, (37, 29, 3)), (2, None, (2, 23, 17, 3)), (3, 1, (31, 16, 1)),
+                                             (2, "rotate", (3, 23, 17, 3)), (3, "rotate", (2, 19, 16, 1))])
 def test_strips_over_gloo(world, dst, shape):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -93,10 +109,20 @@ def test_strips_over_gloo(world, dst, shape):
     for r, ok, shp in strips:
         if shp is not None:
             assert shp[-3] == H * SCALE
+    if dst == "rotate":      # every frame of the batch is held by exactly one rank
+        assert sum(shp[0] for _, _, shp in strips if shp is not None) == shape[0]
     # frame slices are contiguous, disjoint and cover the batch of 5
     assert frames[0][1] == 0 and frames[-1][2] == 5
     for a, b in zip(frames, frames[1:]):
         assert a[2] == b[1]
+
+
+def test_single_process_fills_out():
+    """world == 1: a caller-supplied `out` is filled and returned."""
+    img = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (9, 8, 1), dtype=np.uint8))
+    out = torch.zeros((36, 32, 1), dtype=torch.uint8)
+    got = sr_strips(img, lambda band, r0, y0, y1, H: band.repeat_interleave(SCALE, 0).repeat_interleave(SCALE, 1), SCALE, HALO, out=out)
+    assert got is out and torch.equal(out, img.repeat_interleave(SCALE, 0).repeat_interleave(SCALE, 1))
 
 
 def test_slicing_helpers():

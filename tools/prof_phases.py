@@ -43,7 +43,7 @@ def main():
     waves = d[8]
     total = sum(d[:6])
     clock = d[6] / max(d[7], 1) * 0.1
-    tiles = reps * args.frames * 30 * 68
+    tiles = reps * args.frames * 120 * 270 / 16.0      # wave tiles per wave... (16 x 4 pixels each)
     rec = {"kernel": "stage_tube2_kernel (probe build t2prof)", "frames": args.frames, "launches": reps, "waves": waves,
            "in_kernel_clock_ghz": round(clock, 3), "wave_lifetime_us": round(d[6] / max(waves, 1) / clock / 1e3, 1),
            "phases": [{"phase": PHASES[k], "share": round(d[k] / total, 4), "cycles_per_tile_and_wave": round(d[k] / (tiles * 16.0), 1)} for k in range(6)]}
