@@ -60,6 +60,7 @@ struct mulut_ctx {
     int k1_N = 0, k1_W = 0, k1_H = 0, k1_tiles_x = 0, k1_tiles_y = 0, k1_oy0 = 0, k1_oy1 = 0;   // ... of this shape ...
     const uint8_t *k1_out = nullptr;                                      // ... written to this buffer
     int stat_from_k1 = 1;          // tuning "stat_from_first_stage": the final stage's statistic looks only at tiles the first stage marked
+    int fix_variant = 0;           // tuning "fix_kernel"
     int tube2 = 1;                 // tuning "tube_pipelined": 1 = stage_tube2_kernel (hand-scheduled LDS reads) where the mode list has one, 0 = stage_tube_kernel
     int dirty_to_slab = 0;         // tuning "dirty_to_slab": 1 = the tube kernel's dirty samples are computed by the anchor-slab kernels, 0 = by the fix-up kernel
                                    // (measured on D-natural, 0.9 % dirty samples: 244 vs 226 us/frame -- the extra items cost the slab kernel a second
@@ -565,7 +566,10 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
                 a.k1_hdr = ctx->tlist;
                 a.k1_tiles_x = ctx->k1_tiles_x; a.k1_tiles_y = ctx->k1_tiles_y; a.k1_oy0 = ctx->k1_oy0;
             }
-            HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st, slab ? ctx->det_thist : nullptr));
+            // the control words of the detailed-tile path are cleared before the statistic: it raises ctl[kDetAny] when it marks a tile
+            if (slab && !ctx->dirty_to_slab) HIP_TRY(ctx, hipMemsetAsync(ctx->det_ctl, 0, kDetCtlDwords * sizeof(uint32_t), st));
+            HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st, slab ? ctx->det_thist : nullptr,
+                                          (slab && !ctx->dirty_to_slab) ? ctx->det_ctl + kDetAny : nullptr));
             a.k1_hdr = nullptr;
         }
         a.verdict = ctx->verdict;
@@ -589,10 +593,10 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
             d.ctl = ctx->det_ctl; d.items = ctx->det_items; d.desc = ctx->det_desc; d.blocks = ctx->det_blocks;
             d.thist = ctx->det_thist; d.tpos = ctx->det_tpos; d.dlist = ctx->det_dlist;
             if (ctx->dirty_to_slab) { d.dirty_count = ctx->dirty; d.dirty_list = ctx->dirty + 16; }
-            else HIP_TRY(ctx, hipMemsetAsync(ctx->det_ctl, 0, kDetCtlDwords * sizeof(uint32_t), st));
+
             for (int m = 0; m < 3; ++m) d.slab[m] = m < ctx->n_modes ? ctx->tab[stage - 1][pattern_id(ctx->modes[m])].slab : nullptr;
             HIP_TRY(ctx, launch_detail_slab(a, d, mode, ctx->num_cus, st));
-            HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
+            HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st, ctx->fix_variant));
             return MULUT_OK;
         }
         StageArgs g = a;
@@ -602,7 +606,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         g.tiles_y = (oy1 - oy0 + gh - 1) / gh;
         g.verdict_take = 1;
         HIP_TRY(ctx, launch_stage_up(g, u, mode, st));
-        if (tube) HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
+        if (tube) HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st, ctx->fix_variant));
         return MULUT_OK;
     }
     if (tube) {
@@ -611,7 +615,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
             a.site_flags = ctx->sflags;
         }
         MAIN_KERNEL(ctx, stage, st, tube_launch(ctx, a, b, mode, st));
-        HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st));
+        HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st, ctx->fix_variant));
     } else if (x) MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
     else MAIN_KERNEL(ctx, stage, st, launch_stage_band(a, b, mode, ctx->num_cus, st));
     return MULUT_OK;
@@ -895,6 +899,11 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "stat_from_first_stage")) {
         if (value < 0 || value > 1) return MULUT_EINVAL;
         ctx->stat_from_k1 = value;
+        return MULUT_OK;
+    }
+    if (!strcmp(key, "fix_kernel")) {      // fix-up of the u == 4 tube kernels: 0 = one pass per lane, 1 = one entry per thread
+        if (value < 0 || value > 1) return MULUT_EINVAL;
+        ctx->fix_variant = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "tube_pipelined")) {

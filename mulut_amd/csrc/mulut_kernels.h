@@ -89,7 +89,7 @@ enum K2Out { kOutGeneric = 0, kOutPlanarU4 = 1, kOutPackedRGBU4 = 2 };
 // readable padding (StageArgs::in_padded: the pipeline's own intermediate images are), because the 8 bytes of the image's
 // very last rows would otherwise end beyond the buffer.
 constexpr int kSlabXLo = 2, kSlabXHi = 6, kSlabXHiPadded = 2;
-constexpr int kDetCount = 0, kDetStart = 16, kDetDirty = 32, kDetTiles = 62, kDetItems = 63, kDetDirtyCursor = 64, kDetDirtyBase = 80, kDetCtlDwords = 128;      // dword offsets in DetailArgs::ctl
+constexpr int kDetCount = 0, kDetStart = 16, kDetDirty = 32, kDetAny = 61, kDetTiles = 62, kDetItems = 63, kDetDirtyCursor = 64, kDetDirtyBase = 80, kDetCtlDwords = 128;      // dword offsets in DetailArgs::ctl
 __host__ __device__ inline int slab_x_hi(const StageArgs &a) { return a.in_padded ? kSlabXHiPadded : kSlabXHi; }
 struct DetailArgs {
     uint32_t *ctl;             // kDetCtlDwords: [0..15] samples per anchor MSB, [16..31] list starts, [32..47] dirty samples per anchor MSB (zero on entry),
@@ -138,7 +138,7 @@ const char *stage_tube_name(int out_mode);
 bool stage_tube2_supported(const StageArgs &a);
 hipError_t launch_stage_tube2(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 // recompute the pixels listed in a.fix_list[0 .. *a.fix_count) from the full tables (u == 4)
-hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st);
+hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st, int variant = 0);
 // detailed tiles (a.verdict[tile] == 1, 64x16 tiling) of a u == 4 final stage from anchor slabs in LDS: bucket, plan,
 // fill, slab and retile kernels; border columns are appended to a.fix_list.  d.thist comes from launch_tile_stat.
 bool detail_slab_supported(const StageArgs &a);
@@ -148,7 +148,9 @@ size_t detail_blocks_count(const StageArgs &a);
 hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_mode, int num_cus, hipStream_t st);
 // per-tile smooth/detailed verdict for the hybrid final stage (tiles of stage_band_tile())
 // thist (optional): [tile][16] anchor-MSB histograms of the detailed tiles for launch_detail_slab
-hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st, uint16_t *thist = nullptr);
+// any (optional): set to 1 when some tile is marked detailed (DetailArgs::ctl + kDetAny, zeroed by the caller BEFORE this launch): the
+// kernels of the detailed-tile path leave at once while it is 0
+hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st, uint16_t *thist = nullptr, uint32_t *any = nullptr);
 // per-pixel tube flags (bit c: channel c's 5x5 neighbourhood spans > 1 MSB step) + the same per-tile verdict from them
 hipError_t launch_site_flags(const StageArgs &a, uint32_t *verdict, uint8_t *flags, uint32_t max_per_1024, hipStream_t st);
 void stage_band_tile(int &tw, int &th);

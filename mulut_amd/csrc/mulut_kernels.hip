@@ -1110,7 +1110,7 @@ __device__ __forceinline__ size_t detail_pos_index(uint32_t tile, uint32_t ntile
 }
 
 template <int TW, int TH>
-__global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *verdict, uint32_t max_oob_per_1024, uint16_t *thist) {
+__global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *verdict, uint32_t max_oob_per_1024, uint16_t *thist, uint32_t *any) {
     constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
     __shared__ uint8_t s_h[3 * PH * PW];
     __shared__ uint32_t s_cnt, s_valid;
@@ -1205,7 +1205,10 @@ __global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *v
     }
     __syncthreads();
     const bool detailed = s_cnt * 1024u > max_oob_per_1024 * s_valid;       // workgroup-uniform
-    if (threadIdx.x == 0) verdict[id] = detailed ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        verdict[id] = detailed ? 1u : 0u;
+        if (detailed && any) *any = 1u;      // (every writer stores the same value)
+    }
     // a detailed tile also leaves the anchor-MSB histogram of its samples for the anchor-slab path (launch_detail_slab)
     if (detailed && thist) {
         if (threadIdx.x < 16) s_hist[threadIdx.x] = 0;
@@ -1838,10 +1841,10 @@ __global__ void __launch_bounds__(TW *TH) stage_band_kernel(StageArgs a, BandArg
 constexpr int KB_TW = 64, KB_TH = 16;
 void stage_band_tile(int &tw, int &th) { tw = KB_TW; th = KB_TH; }
 
-hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st, uint16_t *thist) {
+hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st, uint16_t *thist, uint32_t *any) {
     const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;   // a.tiles_* must be the 64x16 tiling
     if (nb <= 0 || nb > 0x7fffffffLL || a.C > 3) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((tile_stat_kernel<KB_TW, KB_TH>), dim3((unsigned)nb), dim3(256), 0, st, a, verdict, max_oob_per_1024, thist);
+    hipLaunchKernelGGL((tile_stat_kernel<KB_TW, KB_TH>), dim3((unsigned)nb), dim3(256), 0, st, a, verdict, max_oob_per_1024, thist, any);
     return hipGetLastError();
 }
 const char *stage_band_name(int out_mode) {
@@ -2475,10 +2478,74 @@ __global__ void __launch_bounds__(256) stage_up_fix_kernel(StageArgs a) {
     }
 }
 
-hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st) {
+// The same fix-up with one PASS per lane.  The list is short (~0.1 % of the samples on smooth content) and a sample's 12 passes
+// are independent: the kernel above serialises them in one thread -- twelve dependent trips to L2 per entry, 110 us per launch for
+// ~50 k entries with most of the chip idle.  Here a 16-lane group takes an entry; lane p computes passes p, p + 16, ... of the
+// sample (mode p / 4, rotation p % 4): four neighbour bytes and five 16-byte rows straight from global memory -- two dependent
+// trips for the whole sample -- multiplied out per row element and added into the group's 16 LDS sums at the block positions
+// that rotation maps the elements to; lane e then finishes block position e (divide, round half to even, clip) and stores its byte.
+__global__ void __launch_bounds__(256) stage_up_fix2_kernel(StageArgs a) {
+    __shared__ int s_sum[16][16];
+    const uint32_t count = *a.fix_count;
+    const int grp = (int)(threadIdx.x >> 4), ln = (int)(threadIdx.x & 15);
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    const int unbias = 128 * kQ * 4 * a.M - a.bias_num;
+    // a group's 16 lanes sit in one wave and LDS serves a wave's operations in order: no workgroup barrier anywhere, the groups run
+    // independently (the fences only keep the compiler from moving the LDS accesses across each other)
+    for (uint32_t i = blockIdx.x * 16u + (uint32_t)grp; i < count; i += gridDim.x * 16u) {
+        // entry: pixel id (n H + y) W + x in the low 30 bits, channel in the top two (3 = every channel)
+        const uint32_t ent = a.fix_list[i], id = ent & 0x3FFFFFFFu, only = ent >> 30;
+        const int x = (int)(id % (uint32_t)a.W), y = (int)((id / (uint32_t)a.W) % (uint32_t)a.H), n = (int)(id / ((uint32_t)a.W * (uint32_t)a.H));
+        const int c_lo = only == 3u ? 0 : (int)only, c_hi = only == 3u ? a.C : (int)only + 1;
+        for (int c = c_lo; c < c_hi; ++c) {
+            s_sum[grp][ln] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            auto px = [&](int dy, int dx) {
+                const int gy = imin(imax(y + dy, ylo), yhi), gx = imin(imax(x + dx, 0), a.W - 1);
+                return (int)*view_addr(a.in, n, c, gy, gx);
+            };
+            const int va = px(0, 0);
+            for (int p = ln; p < 4 * a.M; p += 16) {
+                const int m = p >> 2, r = p & 3;
+                int dy, dx, v[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    sample_offset(r, a.di[m][k], a.dj[m][k], dy, dx);
+                    v[k] = px(dy, dx);
+                }
+                int idx[5], w[5];
+                simplex4(va, v[0], v[1], v[2], idx, w);
+                const uint4 *tab = (const uint4 *)a.lut[m];
+                uint32_t row[5][4];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const uint4 t = tab[idx[j]];
+                    row[j][0] = t.x; row[j][1] = t.y; row[j][2] = t.z; row[j][3] = t.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int sum = 0;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) sum += w[j] * (int)((row[j][e >> 2] >> (8 * (e & 3))) & 0xFFu);
+                    // block position (sy, sx) that rotation r gives row element e (the inverse of row_elem)
+                    const int pos = r == 0 ? e : r == 1 ? (e & 3) * 4 + 3 - (e >> 2) : r == 2 ? 15 - e : (3 - (e & 3)) * 4 + (e >> 2);
+                    atomicAdd(&s_sum[grp][pos], sum);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t b = rhe_clip_u8(s_sum[grp][ln] - unbias, a.div);
+            *const_cast<uint8_t *>(view_addr(a.out, n, c, y * 4 + (ln >> 2), x * 4 + (ln & 3))) = (uint8_t)b;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // sums read before the next round clears them
+        }
+    }
+}
+
+// variant (tuning "fix_kernel"): 0 = one pass per lane (stage_up_fix2_kernel), 1 = one entry per thread (stage_up_fix_kernel)
+hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st, int variant) {
     if (a.C > 3 || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(4 * num_cus)), block(256);
-    if (out_mode == kOutPlanarU4) hipLaunchKernelGGL((stage_up_fix_kernel<kOutPlanarU4>), grid, block, 0, st, a);
+    if (variant == 0) hipLaunchKernelGGL(stage_up_fix2_kernel, dim3((unsigned)(8 * num_cus)), block, 0, st, a);
+    else if (out_mode == kOutPlanarU4) hipLaunchKernelGGL((stage_up_fix_kernel<kOutPlanarU4>), grid, block, 0, st, a);
     else if (out_mode == kOutPackedRGBU4 && a.C == 3) hipLaunchKernelGGL((stage_up_fix_kernel<kOutPackedRGBU4>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((stage_up_fix_kernel<kOutGeneric>), grid, block, 0, st, a);
     return hipGetLastError();
@@ -2981,6 +3048,7 @@ __device__ __forceinline__ uint4 lds_u128(uint32_t addr) {
 // absolute positions in the id lists (exclusive scan over tiles per anchor MSB, in place), the 16 totals become list
 // starts and work items, and the detailed tiles are listed (dlist) -- no atomics, so the lists are deterministic.
 __global__ void __launch_bounds__(1024) detail_plan_kernel(DetailArgs d, const uint32_t *verdict, uint32_t ntiles, uint32_t want_items) {
+    if (!d.dirty_list && d.ctl[kDetAny] == 0u) return;      // no tile was marked detailed (workgroup-uniform): nothing to plan, fill, compute or retile
     __shared__ uint32_t s_wave[16][17];
     __shared__ uint32_t s_start[17], s_item0[17], s_isz;
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
@@ -3116,6 +3184,7 @@ __global__ void __launch_bounds__(1024) detail_plan_kernel(DetailArgs d, const u
 // a sample inside its tile's share of a list comes from an LDS counter); pixels in the image's border columns go to the
 // pixel fix-up list instead
 __global__ void __launch_bounds__(256) detail_fill_kernel(StageArgs a, DetailArgs d) {
+    if (!d.dirty_list && d.ctl[kDetAny] == 0u) return;      // no tile was marked detailed (workgroup-uniform): nothing to plan, fill, compute or retile
     constexpr int TW = KB_TW, TH = KB_TH, PER = 3 * TW * TH / 256;
     static_assert(TW == 64 && TH == 16, "sample ids assume the 64x16 verdict tile");
     __shared__ uint32_t s_rank[16], s_base[16], s_fix[2];
@@ -3479,6 +3548,7 @@ __device__ __forceinline__ void slab_mode(const StageArgs &a, int pat, uint32_t 
 
 __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, DetailArgs d) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (!d.dirty_list && d.ctl[kDetAny] == 0u) return;      // no tile was marked detailed (workgroup-uniform)
     if (lds_addr_of(smem) != 0u) __builtin_trap();      // the row reads assume the slab pair starts at LDS address 0 (no static LDS here): fail loudly, never leave blocks unwritten
     const uint32_t nitems = d.ctl[kDetItems];
 #if defined(MULUT_VARIANT_slabclk)
@@ -3536,6 +3606,7 @@ __global__ void __launch_bounds__(kSlabNT) stage_slab_kernel(StageArgs a, Detail
 
 template <int OUT>
 __global__ void __launch_bounds__(KB_TW *KB_TH) detail_retile_kernel(StageArgs a, DetailArgs d) {
+    if (!d.dirty_list && d.ctl[kDetAny] == 0u) return;      // no tile was marked detailed (workgroup-uniform)
     const uint32_t ndet = d.ctl[kDetTiles];
     const int tx = threadIdx.x % KB_TW, ty = threadIdx.x / KB_TW;
     for (uint32_t li = blockIdx.x; li < ndet; li += gridDim.x) {
