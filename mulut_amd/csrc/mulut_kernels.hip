@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
         const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
         const uint32_t *src = (const uint32_t *)b.band[m];
         uint32_t *dst = (uint32_t *)(smem + pat * BB);
-        for (int i = threadIdx.x; i < BB / 4; i += NT) dst[i] = src[i];
+        for (int i = (int)threadIdx.x; i < BB / 4; i += NT) dst[i] = src[i];
     }
     const int ntiles = a.N * a.tiles_x * a.tiles_y;
     const int G = gridDim.x;
@@ -802,13 +802,23 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
     const bool al4 = ((a.W | a.in.sY) & 3) == 0 && (a.in.sN & 3) == 0 && (((uintptr_t)a.in.p) & 3) == 0;
     const bool hwc3 = al4 && a.C == 3 && a.in.sC == 1 && a.in.sX == 3;     // packed RGB rows: 12-byte groups of four pixels
     const bool planar = al4 && a.in.sX == 1 && (a.in.sC & 3) == 0;          // planar rows: dwords of four pixels
-    const int tx4 = (int)(threadIdx.x % (TW / 4)) * 4, ty0 = (int)(threadIdx.x / (TW / 4));
+    // per-thread index terms are re-derived from an opaque copy of the thread id wherever a loop needs them: hoisted out of the tile
+    // loop they would live across the pixel loop (which needs every register) -- in scratch, i.e. as HBM traffic
+    auto opaque_tid = [&]() {
+        int t = (int)threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
 
     for (int tile = first; tile < last; tile += step) {
         int n, y0, x0;
         decode_tile(a, tile, n, y0, x0, TW, TH);
         __syncthreads();      // everyone is done with the previous tile (and, first trip, the bands are staged)
-        if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+        if (threadIdx.x == 0) {
+            uint32_t z = 0;
+            asm volatile("" : "+v"(z));      // made here: the compiler otherwise keeps a zero pair live across the whole kernel -- in scratch
+            s_cnt[0] = z; s_cnt[1] = z;
+        }
         constexpr int GR = (TW + 8) / 4;            // 18 four-pixel groups cover image columns x0-4 .. x0+67
         // a group of four pixels of one image row, as two packed byte pairs per channel (edge columns replicated)
         auto group_hwc = [&](int row, int g, uint32_t (&bp)[6]) {
@@ -842,14 +852,14 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
             if (tile == 0 && threadIdx.x == 0 && a.tile_count) a.tile_count[2] = 1u;      // "the marks mean something" (for the final stage's statistic)
             uint32_t far = 0, seen = 0;
             if (hwc3) {
-                for (int i = threadIdx.x; i < (PH / 4) * GR; i += NT) {
+                for (int i = opaque_tid(); i < (PH / 4) * GR; i += NT) {
                     uint32_t bp[6];
                     group_hwc(4 * (i / GR) + 1, i % GR, bp);
                     far += far_apart(bp[0], bp[1]) + far_apart(bp[2], bp[3]) + far_apart(bp[4], bp[5]);
                     seen += 3;
                 }
             } else {
-                for (int i = threadIdx.x; i < a.C * (PH / 4) * GR; i += NT) {
+                for (int i = opaque_tid(); i < a.C * (PH / 4) * GR; i += NT) {
                     uint32_t p01, p23;
                     group_planar(i / (GR * (PH / 4)), 4 * ((i / GR) % (PH / 4)) + 1, i % GR, p01, p23);
                     far += far_apart(p01, p23);
@@ -877,21 +887,21 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
             if (4 * g + 1 < PW) dst[1] = c23;          // tile columns 4g, 4g+1
         };
         if (hwc3) {
-            for (int i = threadIdx.x; i < PH * GR; i += NT) {
+            for (int i = opaque_tid(); i < PH * GR; i += NT) {
                 const int g = i % GR, row = i / GR;
                 uint32_t bp[6];
                 group_hwc(row, g, bp);
                 put4(0, row, g, bp[0], bp[1]); put4(1, row, g, bp[2], bp[3]); put4(2, row, g, bp[4], bp[5]);
             }
         } else if (planar) {
-            for (int i = threadIdx.x; i < a.C * PH * GR; i += NT) {
+            for (int i = opaque_tid(); i < a.C * PH * GR; i += NT) {
                 const int g = i % GR, row = (i / GR) % PH, c = i / (GR * PH);
                 uint32_t p01, p23;
                 group_planar(c, row, g, p01, p23);
                 put4(c, row, g, p01, p23);
             }
         } else {
-            for (int i = threadIdx.x; i < a.C * PH * PW; i += NT) {
+            for (int i = opaque_tid(); i < a.C * PH * PW; i += NT) {
                 const int px = i % PW, row = (i / PW) % PH, c = i / (PW * PH);
                 const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
                 const int gx = imin(imax(x0 + px - kHalo, 0), a.W - 1);
@@ -901,7 +911,10 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
         __syncthreads();      // tile in place
 #pragma clang loop unroll(disable)
         for (int half = 0; half < TH * (TW / 4) / NT; ++half) {
-        if (y0 + ty0 + half * (NT / (TW / 4)) >= a.oy1 || x0 + tx4 >= a.W) continue;          // (no barrier below this point inside the trip)
+        {
+            const int t = opaque_tid();
+            if (y0 + t / (TW / 4) + half * (NT / (TW / 4)) >= a.oy1 || x0 + (t % (TW / 4)) * 4 >= a.W) continue;          // (no barrier below this point inside the trip)
+        }
         // Thread coordinates are re-derived from an opaque copy of the thread id wherever they are needed: whatever is
         // computed from them before the pixel loop and used after it would otherwise be parked in scratch around the loop
         // (it needs every register), and scratch of 400k threads does not stay in L2 -- it was 0.7 GB of HBM writes per launch.
@@ -2675,6 +2688,13 @@ __host__ __device__ constexpr int t2_nb(int pat, int r, int k, int sign) {
 }
 __host__ __device__ constexpr int t2_imm(int pat) { return pat * kTubeBandBytes - tube_bias(pat); }
 
+// float of the signed 16-bit value in the low half of x: one SDWA convert with sign extension
+__device__ __forceinline__ float t2_f32_of_i16(uint32_t x) {
+    float f;
+    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(f) : "v"(x));
+    return f;
+}
+
 template <int PAT>
 __device__ __forceinline__ void t2_index(uint32_t k0, uint32_t ha, uint32_t base_a0, uint32_t pb, uint32_t pc, uint32_t pd, T2Pair &o, uint32_t &dirty) {
     constexpr uint32_t SB = kTubeSB * 16, SC = kTubeSC * 16, SD = kTubeSD * 16;
@@ -2758,7 +2778,7 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
     const int step = by_xcd ? (G >> 3) : G;
     if (first >= last) return;              // workgroup-uniform
     const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
-    const bool dw_ok = a.in.sX == 1 && ((a.W | a.in.sY | a.in.sC) & 3) == 0 && (a.in.sN & 3) == 0 && (((uintptr_t)a.in.p) & 3) == 0;
+    const bool dw_ok = __builtin_amdgcn_readfirstlane((int)(a.in.sX == 1 && ((a.W | a.in.sY | a.in.sC) & 3) == 0 && (a.in.sN & 3) == 0 && (((uintptr_t)a.in.p) & 3) == 0)) != 0;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint8_t *img = smem + 3 * kTubeBandBytes + wave * kT2WaveTileBytes;      // this wave's image of pixel codes
 
@@ -2857,19 +2877,29 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
     while (item >= 0) {
         const int nxt_item = grab();
         fetch(nxt_item, pix);
-        int n, y0, x0;
-        origin(item, n, y0, x0);
-        int lane2 = (int)(threadIdx.x & 63);
-        asm volatile("" : "+v"(lane2));
-        const int lx = lane2 % kT2W, ly = lane2 / kT2W;
-        const int y = y0 + ly, x = x0 + lx;
+        // the site of this lane; re-derived (from an opaque copy of the lane id) wherever it is needed: a value computed before the
+        // pipelined loop and used after it would be parked in scratch (the loop needs every register)
+        auto site = [&](int &n_, int &y_, int &x_, int &lx_, int &ly_) {
+            int y0, x0;
+            origin(item, n_, y0, x0);
+            int l = (int)(threadIdx.x & 63);
+            asm volatile("" : "+v"(l));
+            lx_ = l % kT2W; ly_ = l / kT2W;
+            y_ = y0 + ly_; x_ = x0 + lx_;
+        };
+        int n, y, x, lx, ly;
+        site(n, y, x, lx, ly);
         T2_STAMP(0);       // work item drawn, next tile's fetch issued
         if (y < a.oy1 && x < a.W) {
             // LDS byte address of the 5x5 window corner (y-2, x-2) of this site, channel 0
             uint32_t win = (uint32_t)(3 * kTubeBandBytes + wave * kT2WaveTileBytes + 2 * (ly * PW + lx + kTubeHaloX - kHalo));
             // finished channels wait in LDS for the RGB interleave (a uint4 per thread and channel): registers are what the
             // pipelined loop below is short of
-            uint4 *park = (uint4 *)(smem + 3 * kTubeBandBytes + 16 * kT2WaveTileBytes) + threadIdx.x;
+            auto park = [&]() {
+                int t = (int)threadIdx.x;
+                asm volatile("" : "+v"(t));
+                return (uint4 *)(smem + 3 * kTubeBandBytes + 16 * kT2WaveTileBytes) + t;
+            };
             uint32_t dmask = 0u, dirty = 0u, dirty_n = 0u;
             uint32_t o[4] = {0u, 0u, 0u, 0u};
             uint32_t pb, pc, pd, ca;
@@ -2892,7 +2922,16 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                 t2_index<p0>(k0, ha, ba0, pb, pc, pd, nxt, dirty);
             }
             RotAcc<4> acc;
-            acc.clear();
+            // the (0,2) fields start at -unbias (the rows are value + 128: unbias = 128 * 16 * 4 M <= 24576) where the epilogue works on K
+            auto acc_start = [&]() {
+                acc.clear();
+                if constexpr (OUT != kOutGeneric) {
+                    const uint32_t nb = pk_dup((uint32_t)(65536 - 128 * kQ * 4 * M));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc.lo02[k] = acc.hi02[k] = nb;
+                }
+            };
+            acc_start();
             T2_STAMP(1);   // pipeline prologue: neighbours of pairs 0 and 1, index math, first rows requested
 #pragma clang loop unroll(disable)
             for (int c = 0; c < a.C; ++c, win += kT2Chan) {
@@ -2922,20 +2961,45 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                     cur = nxt;
                     nxt = nn;
                 });
-                if constexpr (OUT == kOutPackedRGBU4) {
-                    tube_finish_rows(a, acc, o);
-                    if (c < 2) park[c * NT] = make_uint4(o[0], o[1], o[2], o[3]);
+                if constexpr (OUT != kOutGeneric) {
+                    // Epilogue on the numerators themselves: the (0,2) accumulators started at -unbias (mod 2^16), so the sum of the
+                    // two fields of a block position IS K = 16 M pred (mod 2^16, |K| < 2^15).  Per byte: one 16-bit-select add, one
+                    // sign-extending convert, one multiply by fl(1/d), one v_cvt_pk_u8_f32 (it rounds to nearest even and saturates:
+                    // tools/probe_cvt.hip).  Exact for this divisor: StageArgs::use_f32, proven by brute force at configure time.
+                    static_for<0, 4>([&](auto SY) {
+                        constexpr int sy = SY;
+                        const uint32_t s0 = tube_field<4 * sy + 0>(acc.lo02, acc.hi02) + tube_field<12 + sy>(acc.lo13, acc.hi13);
+                        const uint32_t s1 = tube_field<4 * sy + 1>(acc.lo02, acc.hi02) + tube_field<8 + sy>(acc.lo13, acc.hi13);
+                        const uint32_t s2 = tube_field<4 * sy + 2>(acc.lo02, acc.hi02) + tube_field<4 + sy>(acc.lo13, acc.hi13);
+                        const uint32_t s3 = tube_field<4 * sy + 3>(acc.lo02, acc.hi02) + tube_field<0 + sy>(acc.lo13, acc.hi13);
+                        uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(t2_f32_of_i16(s0) * a.inv_d, 0u, 0u);
+                        r = __builtin_amdgcn_cvt_pk_u8_f32(t2_f32_of_i16(s1) * a.inv_d, 1u, r);
+                        r = __builtin_amdgcn_cvt_pk_u8_f32(t2_f32_of_i16(s2) * a.inv_d, 2u, r);
+                        r = __builtin_amdgcn_cvt_pk_u8_f32(t2_f32_of_i16(s3) * a.inv_d, 3u, r);
+                        o[sy] = r;
+                    });
+                    if constexpr (OUT == kOutPackedRGBU4) {
+                        if (c < 2) park()[c * NT] = make_uint4(o[0], o[1], o[2], o[3]);
+                    } else {
+                        int n2, y2, x2, lx2, ly2;
+                        site(n2, y2, x2, lx2, ly2);
+#pragma unroll
+                        for (int sy = 0; sy < 4; ++sy) *(uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n2, c, y2 * 4 + sy, x2 * 4)) = o[sy];
+                    }
                 } else {
-                    finish_channel<4, OUT>(a, acc, n, c, y, x, o);
+                    int n2, y2, x2, lx2, ly2;
+                    site(n2, y2, x2, lx2, ly2);
+                    finish_channel<4, OUT>(a, acc, n2, c, y2, x2, o);
                 }
-                acc.clear();
+                acc_start();
                 dmask |= (dirty != 0u ? 1u : 0u) << c;
                 dirty = dirty_n;
                 dirty_n = 0u;
             }
             T2_STAMP(2);   // the channels: 12 passes + epilogue each
+            site(n, y, x, lx, ly);
             if constexpr (OUT == kOutPackedRGBU4) {
-                const uint4 r = park[0], g = park[NT];
+                const uint4 r = park()[0], g = park()[NT];
                 const uint32_t oR[4] = {r.x, r.y, r.z, r.w}, oG[4] = {g.x, g.y, g.z, g.w};
                 store_rgb<4>(a, n, y, x, oR, oG, o);
             }
@@ -2979,7 +3043,10 @@ static int tube2_pats(const StageArgs &a) {
     for (int m = 0; m < a.M; ++m) pats |= (a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0) << (2 + 2 * m);
     return pats == kT2PatsSDY ? pats : 0;
 }
-bool stage_tube2_supported(const StageArgs &a) { return a.C <= 3 && a.M <= 3 && a.site_flags == nullptr && tube2_pats(a) != 0; }
+bool stage_tube2_supported(const StageArgs &a) {
+    // the float epilogue must be exact for the divisor (StageArgs::use_f32, proven at configure time), the bias the numerator bias of a final stage
+    return a.C <= 3 && a.M <= 3 && a.site_flags == nullptr && tube2_pats(a) != 0 && a.use_f32 && a.bias_num == 0;
+}
 
 template <int OUT>
 static hipError_t launch_tube2_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {

@@ -5,7 +5,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 K=$1; shift
 D=$R/build/asm; mkdir -p $D
-( cd $D && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 "$@" -save-temps=obj -c $R/mulut_amd/csrc/mulut_kernels.hip -o $D/k.o 2>&1 | grep -v "reserved registers" | grep -E "error|warning" | head -20 )
+( cd $D && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 "$@" -save-temps=obj -c $R/mulut_amd/csrc/mulut_kernels.hip -o $D/k.o 2>&1 | grep -v "reserved registers" | grep -E "error|warning: v|failed" | head -20 )
 S=$D/mulut_kernels-hip-amdgcn-amd-amdhsa-gfx950.s
 first=""
 for N in $(grep -o "^_Z[A-Za-z0-9_]*$K[A-Za-z0-9_]*:" $S | tr -d ':'); do
