@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=8, help="LR frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=32, help="LR frames per GPU per step (32: a 20-step timed region lasts ~0.17 s)")
     ap.add_argument("--lr-h", type=int, default=1080)
     ap.add_argument("--lr-w", type=int, default=1920)
     ap.add_argument("--dist", choices=["natural", "noise", "real"], default="natural",
@@ -223,10 +223,11 @@ def main():
             el = float(t.item())
         return el
 
-    if args.config == 5:
-        return config5(args, world, rank, local, timed)
-    if args.config == 4:
-        return config4(args, world, rank, local, timed)
+    if args.config in (4, 5):
+        rec = (config5 if args.config == 5 else config4)(args, world, rank, local, timed)
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+        return
 
     eng = MuLUTEngine(local).configure(STAGES, MODES, SCALE, 4).set_lut_dict(luts)
     eng.reserve(F, H, W, 3)
@@ -276,17 +277,27 @@ def main():
         counters = load_profile_json("kernel_counters.json", workload if world == 1 else None) if world == 1 else None
         traffic = load_profile_json("hbm_traffic.json", workload) if world == 1 else None
         secondary = None
+        issue = load_profile_json("valu_issue.json")
         if counters:
             k2 = counters["final_stage_kernel"]
+            scale_f = F / float(counters.get("frames", F))       # the counters were collected at counters["frames"] frames per launch
+            insts = k2["valu_wave_insts_per_launch"] * scale_f
+            rate = insts / (k2_ms * 1e-3) / 1e9
+            # peak: what the kernel's OWN instruction stream sustains per SIMD with nothing else in the way (tools/ubench/gen_stream_ubench.py:
+            # the hot loop's VALU instructions, same registers and modifiers, 4 waves per SIMD, in-kernel clock) -- and, beside it, the
+            # guide's 2 cycles per wave64 VALU instruction
+            cpi = issue["stream_cycles_per_valu_inst"] if issue else None
+            clk = issue["stream_clock_ghz"] if issue else None
+            peak_stream = SIMDS * clk / cpi if issue else None
             secondary = {
-                "bound": "valu_issue", "kernel": k2["name"],
-                "achieved": round(k2["valu_wave_insts_per_launch"] / (k2_ms * 1e-3) / 1e9, 2),
-                "peak": round(SIMDS * CLOCK_GHZ / 4, 2), "unit": "G wave-instructions/s",
-                "frac": round(k2["valu_wave_insts_per_launch"] / (k2_ms * 1e-3) / 1e9 / (SIMDS * CLOCK_GHZ / 4), 4),
-                "how": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, profiles/kernel_counters.json, same source hash) / the kernel's "
-                       "event-timed duration in this run; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
-                "valu_insts_per_pass": round(k2["valu_wave_insts_per_launch"] / (sites / 64 * 12), 1),
-                "lds_gather": {"achieved": round(k2.get("lds_bytes_per_launch", 0) / (k2_ms * 1e-3) / 1e9, 1), "peak": round(LDS_PEAK_GBS, 1),
+                "bound": "valu_issue", "kernel": k2["name"], "achieved": round(rate, 2), "unit": "G wave-instructions/s",
+                "peak": round(peak_stream, 2) if issue else None, "frac": round(rate / peak_stream, 4) if issue else None,
+                "peak_how": ("the kernel's own VALU stream as a microbenchmark: %.2f cycles per instruction per SIMD at %.2f GHz in-kernel clock, 4 waves per SIMD "
+                             "(profiles/valu_issue.json, same source hash)" % (cpi, clk)) if issue else "profiles/valu_issue.json missing or stale",
+                "peak_guide_2_cycles": round(SIMDS * CLOCK_GHZ / 2, 1), "frac_of_guide_peak": round(rate / (SIMDS * CLOCK_GHZ / 2), 4),
+                "how": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, profiles/kernel_counters.json, same source hash) / the kernel's event-timed duration in this run",
+                "valu_insts_per_pass": round(insts / (sites / 64 * 12), 1),
+                "lds_gather": {"achieved": round(k2.get("lds_bytes_per_launch", 0) * scale_f / (k2_ms * 1e-3) / 1e9, 1), "peak": round(LDS_PEAK_GBS, 1),
                                "unit": "GB/s", "bytes_per_lr_sample": 12 * 5 * 32,
                                "note": "row gathers of the final stage: 12 passes x 5 rows x 32 B (16-bit fields) per LR sample"},
             }
@@ -304,7 +315,7 @@ def main():
                          "traffic": traffic.get("pipeline_bytes_per_step") if traffic else None,
                          "algorithmic_bytes_per_step": alg,
                          "stage_ms": [round(float(v), 4) for v in ms_stage],
-                         "dominant_kernel": {"name": "stage_tube_kernel<rgb>" if "tube" in eng.kernel_name(True) else eng.kernel_name(True),
+                         "dominant_kernel": {"name": "stage_tube2_kernel<rgb>" if "tube2" in eng.kernel_name(True) else "stage_tube_kernel<rgb>" if "tube" in eng.kernel_name(True) else eng.kernel_name(True),
                                              "ms": round(k2_ms, 4), "algorithmic_bytes_per_launch": alg_k2,
                                              "achieved": round(alg_k2 / (k2_ms * 1e-3) / 1e9, 2),
                                              "kernel_frac": round(alg_k2 / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -346,9 +357,16 @@ def main():
             if state["printed"]:      # the watchdog fired while the leg was finishing: it owns the output
                 return
             state["printed"] = True
+    extra = None
+    if not args.skip_other and world == 1:
+        del x, out
+        torch.cuda.empty_cache()
+        extra = other_configs(args, world, rank, local, timed)
     if rank == 0:
         if strips:
             rec["config"]["strips_gather"] = strips
+        if extra:
+            rec["config"]["other_configs"] = extra
         print(json.dumps(rec), flush=True)
     if dist_on:
         torch.distributed.destroy_process_group()
@@ -429,7 +447,7 @@ def config3(args, eng, world, rank, dist_on, backend, timed):
     return rec
 
 
-def config4(args, world, rank, local, timed):
+def config4(args, world, rank, local, timed, steps=None):
     """BASELINE config 4: one LUT fine-tune step (forward + backward HIP kernels + Adam) at bs 256 of 1x48x48 crops, 2-stage sdy x4."""
     import tempfile
     import torch
@@ -454,26 +472,41 @@ def config4(args, world, rank, local, timed):
         opt.step()
     for _ in range(max(args.warmup, 3)):
         step()
-    el = timed(step, args.steps)
-    if rank == 0:
-        ms = el / args.steps * 1e3
-        print(json.dumps({
-            "metric": "LR Mpixels/sec through one LUT fine-tune step (forward + backward + Adam), 2-stage sdy x4", "value": round(world * bs * crop * crop * args.steps / el / 1e6, 3),
-            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(ms, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config 4: bs 256 x 1x48x48 crops of the D-natural field per GPU per step, shipped tables as the start point",
-                       "note": "replicas only: each rank trains its own copy (a data-parallel all-reduce of the six table gradients is not built)",
-                       "reference_logged": "7.0 s/iter at batch 320 (models/sr_x2sdy/lutft.log), unspecified 2022 GPU"},
-        }))
+    steps = steps or args.steps
+    el = timed(step, steps)
+    ms = el / steps * 1e3
+    # the backward kernel of the final stage dominates the step; two candidate bounds for it, both from MI355X_MICROARCH.md:
+    # LDS float adds into the tube band (ds_add_f32: one 4-byte lane group op per 2 LDS cycles per CU at best) and the memory-side
+    # float-atomic rate (about 1.3 TB/s of added bytes chip-wide) for the rows outside the band and the flush
+    sites = bs * crop * crop
+    adds = sites * 12 * 5 * 16                     # (site, pass, row, element) float adds into the final-stage tables
+    counters = load_profile_json("finetune_counters.json")
+    return {
+        "metric": "LR Mpixels/sec through one LUT fine-tune step (forward + backward + Adam), 2-stage sdy x4", "value": round(world * bs * crop * crop * steps / el / 1e6, 3),
+        "unit": "Mpix/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 3), "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config 4: bs 256 x 1x48x48 crops of the D-natural field per GPU per step, shipped tables as the start point",
+                   "note": "replicas only: each rank trains its own copy (a data-parallel all-reduce of the six table gradients is not built)",
+                   "reference_logged": "7.0 s/iter at batch 320 (models/sr_x2sdy/lutft.log), unspecified 2022 GPU"},
+        "roofline": {"bound": "lds_atomic", "kernel": "ft_stage_bwd4 (final-stage backward: table gradients summed in an LDS copy of the tube band, flushed once per workgroup and mode)",
+                     "table_gradient_adds_per_step": adds,
+                     "achieved": round(adds / (ms * 1e-3) / 1e9, 2), "unit": "G float adds/s (whole step time as the denominator)",
+                     "peak": round(256 * 32 * CLOCK_GHZ, 1), "peak_how": "256 CUs x 32 ds_add_f32 lanes per LDS cycle (a 4-byte LDS access serves 32 lanes per cycle: MI355X_MICROARCH.md, LDS) x 2.4 GHz",
+                     "frac": round(adds / (ms * 1e-3) / 1e9 / (256 * 32 * CLOCK_GHZ), 4),
+                     "memory_side_float_atomics": {"peak": 1300.0, "unit": "GB/s of added bytes (MI355X_MICROARCH.md, Global float atomics)",
+                                                   "if_every_add_went_to_memory": round(adds * 4 / (ms * 1e-3) / 1e9, 1)},
+                     "counters": counters.get("kernels") if counters else None, "traffic": None},
+    }
 
 
-def config5(args, world, rank, local, timed):
-    """BASELINE config 5: 4-stage sdy x2 cascade on seeded synthetic tables, P1 input, eager launches vs one hipGraph replay."""
+def config5(args, world, rank, local, timed, size=None, steps=None):
+    """BASELINE config 5: 4-stage sdy x2 cascade on seeded synthetic tables, eager launches vs one hipGraph replay."""
     import torch
     from mulut_amd import MuLUTEngine
     stages, scale = 4, 2
     rng = np.random.default_rng(5)
-    F, H, W = args.frames, args.lr_h, args.lr_w
+    F, H, W = size or (args.frames, args.lr_h, args.lr_w)
+    steps = steps or args.steps
     eng = MuLUTEngine(local).configure(stages, MODES, scale, 4)
     for s in range(1, stages + 1):
         for m in MODES:
@@ -486,7 +519,7 @@ def config5(args, world, rank, local, timed):
     out = torch.empty((F, H * scale, W * scale, 3), dtype=torch.uint8, device="cuda")
     for _ in range(args.warmup):
         eng.pipeline(x, out=out)
-    el_eager = timed(lambda: eng.pipeline(x, out=out), args.steps)
+    el_eager = timed(lambda: eng.pipeline(x, out=out), steps)
     eng.set_stage_timing(True)
     eng.pipeline(x, out=out)
     ms_stage = eng.last_stage_ms()
@@ -503,23 +536,41 @@ def config5(args, world, rank, local, timed):
     g.replay()
     torch.cuda.synchronize()
     same = bool(torch.equal(out, want))
-    el_graph = timed(g.replay, args.steps)
-    if rank == 0:
-        sites = F * H * W * 3
-        alg = sites * (1 + scale * scale) + 3 * 83521 * ((stages - 1) + scale * scale)
-        ms = el_graph / args.steps * 1e3
-        print(json.dumps({
-            "metric": "Mpixels/sec SR-x2 4-stage sdy LUT inference, hipGraph replay (HR output pixels)", "value": round(world * F * H * scale * W * scale * args.steps / el_graph / 1e6, 2),
-            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "config 5: 4-stage sdy x2, %d x LR %dx%dx3 -> HR %dx%dx3 per GPU per step, D-%s, seeded synthetic tables"
-                                   % (F, H, W, H * scale, W * scale, args.dist),
-                       "eager_ms_per_step": round(el_eager / args.steps * 1e3, 4), "graph_ms_per_step": round(ms, 4),
-                       "graph_replay_matches_eager": same, "stage_ms": [round(v, 4) for v in ms_stage],
-                       "kernels": [eng.kernel_name(False), eng.kernel_name(True)]},
-            "roofline": {"bound": "hbm", "kernel": "4-stage pipeline", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_step": alg},
-        }))
+    el_graph = timed(g.replay, steps)
+    sites = F * H * W * 3
+    alg = sites * (1 + scale * scale) + 3 * 83521 * ((stages - 1) + scale * scale)
+    ms = el_graph / steps * 1e3
+    return {
+        "metric": "Mpixels/sec SR-x2 4-stage sdy LUT inference, hipGraph replay (HR output pixels)", "value": round(world * F * H * scale * W * scale * steps / el_graph / 1e6, 2),
+        "unit": "Mpix/s", "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "config 5: 4-stage sdy x2, %d x LR %dx%dx3 -> HR %dx%dx3 per GPU per step, D-%s, seeded synthetic tables"
+                               % (F, H, W, H * scale, W * scale, args.dist),
+                   "eager_ms_per_step": round(el_eager / steps * 1e3, 4), "graph_ms_per_step": round(ms, 4),
+                   "graph_replay_matches_eager": same, "stage_ms": [round(v, 4) for v in ms_stage],
+                   "kernels": [eng.kernel_name(False), eng.kernel_name(True)]},
+        "roofline": {"bound": "hbm", "kernel": "4-stage pipeline", "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_step": alg},
+    }
+
+
+def other_configs(args, world, rank, local, timed):
+    """Configs 4 and 5 in brief, for the default line's config.other_configs (the driver only runs the default line)."""
+    out = {}
+    for name, fn in (("config5_p1", lambda: config5(args, world, rank, local, timed, size=(8, 1080, 1920), steps=10)),
+                     ("config5_small_frames", lambda: config5(args, world, rank, local, timed, size=(8, 270, 480), steps=50)),
+                     ("config4", lambda: config4(args, world, rank, local, timed, steps=10))):
+        try:
+            r = fn()
+            keep = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "roofline_frac": r["roofline"]["frac"],
+                    "roofline_bound": r["roofline"]["bound"]}
+            for k in ("eager_ms_per_step", "graph_ms_per_step", "graph_replay_matches_eager", "stage_ms"):
+                if k in r["config"]:
+                    keep[k] = r["config"][k]
+            out[name] = keep
+        except Exception as exc:      # the headline must not depend on these legs
+            out[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    return out
 
 
 if __name__ == "__main__":

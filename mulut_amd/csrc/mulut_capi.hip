@@ -952,6 +952,8 @@ const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
         return ctx->final_kernel == 2 ? stage_band_name(kOutPackedRGBU4)
                : ctx->final_kernel == 3 ? stage_bandx_name(kOutPackedRGBU4)
                : ctx->final_kernel == 5 ? stage_tube_name(kOutPackedRGBU4)
+               : ((ctx->final_kernel == 6 || ctx->final_kernel == 0) && ctx->tube2 && ctx->detail_kernel == 0 && !ctx->site_flags_on && !strcmp(ctx->modes, "sdy"))
+                   ? "hybrid: tile_stat_kernel + stage_tube2_kernel<rgb> (smooth tiles; hand-scheduled LDS pipeline, one 16x4 tile per wave) + stage_slab_kernel (detailed tiles, anchor slabs in LDS)"
                : (ctx->final_kernel == 6 || ctx->final_kernel == 0) ? (ctx->detail_kernel == 0 ? "hybrid: tile_stat_kernel + stage_tube_kernel<rgb> (smooth tiles) + stage_slab_kernel (detailed tiles, anchor slabs in LDS)"
                                            : "hybrid: tile_stat_kernel + stage_tube_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)")
                                         : "hybrid: tile_stat_kernel + stage_bandx_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)";

@@ -2936,8 +2936,10 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
 #pragma clang loop unroll(disable)
             for (int c = 0; c < a.C; ++c, win += kT2Chan) {
                 const bool more = c + 1 < a.C;       // wave-uniform
+                asm volatile("; MULUT_T2_STREAM_BEGIN (tools/ubench/gen_stream_ubench.py cuts the ISA here)");
                 static_for<0, NP>([&](auto PI) {
                     constexpr int p = PI;
+                    if constexpr (p == (NP >= 6 ? 4 : NP - 1)) asm volatile("; MULUT_T2_STREAM_END");      // pairs 0..3: straight-line, no `more` variants
                     constexpr int pat = t2_pat(PATS, p >> 1), R = p & 1;
                     // the pair whose neighbours are fetched now (two pairs ahead) and the pair whose first rows refill the registers
                     constexpr bool t_here = p + 2 < NP;

@@ -36,15 +36,15 @@ def main(d, tag):
         if len(t) == 2:
             t["hbm_bytes"] = t["read_bytes"] + t["write_bytes"]
         traffic[k] = t
-    final = [k for k in pmc if "stage_tube" in k or "stage_up" in k or "tile_stat" in k or "site_flag" in k]
+    final = [k for k in pmc if "stage_tube" in k or "stage_up" in k or "tile_stat" in k or "site_flag" in k or "stage_slab" in k or "detail_" in k]
     tube = [k for k in pmc if "stage_tube" in k]
     first = [k for k in pmc if "stage_u1" in k]
     h = _native.source_hash()
-    kc = {"source_hash": h, "workload": workload, "tag": tag, "kernels": kernels}
+    kc = {"source_hash": h, "workload": workload, "tag": tag, "frames": bench.get("config", {}).get("frames_per_gpu"), "kernels": kernels}
     if tube:
         kc["final_stage_kernel"] = dict(kernels[tube[0]], name=tube[0],
                                         lds_bytes_per_launch=None if kernels[tube[0]]["lds_insts_per_launch"] is None else
-                                        kernels[tube[0]]["lds_insts_per_launch"] * 64 * 16 * 10.0 / 12.4)   # ~10 of 12.4 LDS instructions per pass are 16-byte row reads
+                                        kernels[tube[0]]["lds_insts_per_launch"] * 64 * 16 * 10.0 / 13.4)   # ~10 of 13.4 LDS instructions per pass are 16-byte row reads
     json.dump(kc, open(os.path.join(ROOT, "profiles", "kernel_counters.json"), "w"), indent=1)
     tr = {"source_hash": h, "workload": workload, "tag": tag, "kernels": traffic,
           "final_stage_bytes_per_launch": sum(traffic[k].get("hbm_bytes", 0) for k in final),
