@@ -159,23 +159,22 @@ int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int
                  double *psnr, double *ssim, void *stream);
 
 /* Tuning knobs (never change results).
- * "final_stage_kernel": 0 = auto (= 6 when scale 4 and <= 3 modes), 1 = full-table gather kernel, 2 = compact LDS-band
- *   kernel, 3 = expanded LDS-band kernel (one mode resident), 4 = hybrid of 3 and 1, 5 = tube kernel (the bands of all modes
- *   resident; pixels with a pass outside the tube are recomputed from the full table through a device work list), 6 = hybrid:
- *   a per-tile statistic sends smooth 64x16 tiles to the tube kernel and detailed ones to the detailed-tile path.
+ * "final_stage_kernel" (scale 4, <= 3 modes): 0 = auto (= 6), 1 = full-table gather kernel, 5 = tube kernel on every tile (the tube
+ *   bands of all modes resident in LDS; samples with a pass outside the tube are recomputed from the full table through a device
+ *   work list), 6 = hybrid: a per-tile statistic sends smooth 64x16 tiles to the tube kernel and detailed ones to the
+ *   detailed-tile path.  (2-4: the band / expanded-band kernels of rounds 1-2, retired: MULUT_EINVAL.)
+ * "tube_pipelined": 1 (default) = stage_tube2_kernel where the mode list is "sdy" (every LDS read hand-scheduled, the next pass's
+ *   rows in flight under the current pass's multiply-adds, one 16x4 tile per wave, no workgroup barrier), 0 = stage_tube_kernel.
  * "detail_kernel": the detailed tiles of the hybrid: 0 (default) = anchor slabs in LDS (samples grouped by anchor MSB on the
  *   device, stage_slab_kernel; taken when the stage input is planar, < 2^28 bytes, <= 3 modes), 1 = full-table gather kernel.
- * "dirty_to_slab": 1 = the tube kernel's flagged samples are computed by the anchor-slab kernels too, 0 (default) = by the
- *   fix-up kernel from the full tables.
+ * "fix_kernel": the fix-up of the tube kernels' work list: 0 (default) = one pass per lane, 1 = one entry per thread.
  * "stat_from_first_stage": 1 (default) = when the final stage reads what a content-routing first-stage launch of the same
  *   call wrote, its per-tile statistic looks only at the tiles that launch marked detailed; 0 = at every tile.
- * "hybrid_oob_per_1024": tile threshold of the hybrids (sites out of band per 1024, default 128).
+ * "hybrid_oob_per_1024": tile threshold of the hybrid (sites out of band per 1024, default 128).
  * "first_stage_kernel" (stages with 1-byte rows): 0 = auto (tube kernel; tiles its statistic calls detailed go to the
- *   window kernel, flagged sites are recomputed through a device work list), 1 = one LDS read per neighbour, full table in
- *   LDS, 2 = window kernel (full table in LDS), 3 = tube kernel on every tile.
+ *   window kernel, flagged sites are recomputed through a device work list), 2 = window kernel (full table in LDS) on every
+ *   tile, 3 = tube kernel on every tile.  (1: the first one-read-per-neighbour kernel, retired: MULUT_EINVAL.)
  * "first_stage_detail_per_1024": tile threshold of first_stage_kernel 0 (default 24).
- * "tube_site_flags": 1 = a separate pass (site_flag_kernel) marks the pixels whose 5x5 neighbourhood spans more than one MSB step and
- *   the tube kernel drops its per-pass test (detailed tiles then take the gather kernel); 0 (default) = per-pass tests.
  * Unknown key or value: MULUT_EINVAL.
  * hipGraph capture: call mulut_reserve() for the largest (N, H, W, C) first -- the context's workspace, verdict and work-list
  * buffers are then never reallocated by smaller calls; a LARGER later call reallocates them and invalidates graphs captured

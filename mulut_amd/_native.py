@@ -8,9 +8,11 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 _LIBDIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(_LIBDIR, "libmulut_hip.so")
-SOURCES = ["mulut_kernels.hip", "mulut_capi.hip", "mulut_ft.hip", "mulut_eval.hip"]
-HEADERS = ["mulut_core.h", "mulut_kernels.h", "mulut_tube2_asm.inc", os.path.join("..", "..", "include", "mulut.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall"]
+SOURCES = ["mulut_kernels.hip", "mulut_k1.hip", "mulut_detail.hip", "mulut_capi.hip", "mulut_ft.hip", "mulut_eval.hip"]
+HEADERS = ["mulut_core.h", "mulut_kernels.h", "mulut_dev.h", "mulut_tube2_asm.inc", os.path.join("..", "..", "include", "mulut.h")]
+# -Wno-inline-asm: stage_tube2_kernel names registers ABOVE the register allocator's budget in its asm clobber lists on purpose
+# (tools/gen_tube2_asm.py); -Wno-pass-failed: its occupancy attribute is that budget, not an occupancy the kernel reaches
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-inline-asm", "-Wno-pass-failed"]
 
 # every symbol include/mulut.h declares
 EXPORTS = [

@@ -16,8 +16,6 @@ using namespace mulut;
 
 struct DevTable {
     void *dev = nullptr;    // full table image
-    void *band = nullptr;   // diagonal band image (v_num == 16 only), kBandRows x 16 B
-    void *bandx = nullptr;  // the same rows expanded to 16-bit fields, kBandRows x 32 B
     void *tube = nullptr;   // "tube" band (keys spanning <= 2 MSB steps): v_num 16: expanded to 16-bit fields, two planes of kTubeSlots x 16 B;
                             // v_num 1: one dword per slot (kTube1BandBytes)
     size_t tube_bytes = 0;
@@ -46,10 +44,7 @@ struct mulut_ctx {
     uint32_t *verdict = nullptr;   // per-tile smooth/detailed verdicts of the hybrid final stage
     size_t verdict_tiles = 0;
     uint32_t *fix = nullptr;       // [0] = count, [16...] = entries of the fix-up list (samples recomputed from the full tables)
-    uint32_t *dirty = nullptr;     // same shape: the tube kernel's dirty samples when the anchor-slab path takes them
     size_t fix_cap = 0;            // capacity in ids
-    uint8_t *sflags = nullptr;     // site_flag_kernel's byte per pixel of the final-stage input
-    size_t sflags_cap = 0;
     unsigned long long *dbg = nullptr;   // probe buffer (mulut_debug_read), MULUT_DEBUG_WORDS words, allocated on first use
     uint32_t *det_ctl = nullptr;   // detailed-tile path of the final stage (launch_detail_slab): counters, items, sample ids, blocks
     uint32_t *det_items = nullptr, *det_desc = nullptr, *det_tpos = nullptr, *det_dlist = nullptr;
@@ -62,14 +57,9 @@ struct mulut_ctx {
     int stat_from_k1 = 1;          // tuning "stat_from_first_stage": the final stage's statistic looks only at tiles the first stage marked
     int fix_variant = 0;           // tuning "fix_kernel"
     int tube2 = 1;                 // tuning "tube_pipelined": 1 = stage_tube2_kernel (hand-scheduled LDS reads) where the mode list has one, 0 = stage_tube_kernel
-    int dirty_to_slab = 0;         // tuning "dirty_to_slab": 1 = the tube kernel's dirty samples are computed by the anchor-slab kernels, 0 = by the fix-up kernel
-                                   // (measured on D-natural, 0.9 % dirty samples: 244 vs 226 us/frame -- the extra items cost the slab kernel a second
-                                   // round of ~50 us, more than the gathers of the fix-up kernel; kept as an option)
     int detail_kernel = 0;         // tuning "detail_kernel": 0 = anchor slabs in LDS (when the launch qualifies), 1 = full-table gather kernel
-    int site_flags_on = 0;         // tuning "tube_site_flags": 1 = flags from site_flag_kernel (no per-pass test in the tube kernel: 4 % fewer
-                                   // cycles there, but the conservative 5x5 flags grow the fix-up list and the hybrid gains nothing), 0 = per-pass tests
-    int first_kernel = 0;   // 1-byte-row stages: 0 auto (tube kernel, detailed tiles to the window kernel), 1 the original
-                            // one-site-per-read kernel, 2 window kernel (full table in LDS), 3 tube kernel on every tile
+    int first_kernel = 0;   // 1-byte-row stages: 0 auto (tube kernel, detailed tiles to the window kernel), 2 window kernel (full table in
+                            // LDS) on every tile, 3 tube kernel on every tile
     int u1_detail_per_1024 = 24;   // a tile goes to the full-table kernel when more than this share of its (sampled) 4-pixel groups spans > 1 MSB step
     uint32_t *tlist = nullptr;     // [16 + tile] = 1: the tube kernel left this tile to the full-table kernel
     size_t tlist_cap = 0;
@@ -142,8 +132,6 @@ int mulut_destroy(mulut_ctx *ctx) {
         for (auto &t : st)
         {
             if (t.dev) (void)hipFree(t.dev);
-            if (t.band) (void)hipFree(t.band);
-            if (t.bandx) (void)hipFree(t.bandx);
             if (t.tube) (void)hipFree(t.tube);
             if (t.slab) (void)hipFree(t.slab);
         }
@@ -151,8 +139,6 @@ int mulut_destroy(mulut_ctx *ctx) {
         if (w) (void)hipFree(w);
     if (ctx->verdict) (void)hipFree(ctx->verdict);
     if (ctx->fix) (void)hipFree(ctx->fix);
-    if (ctx->dirty) (void)hipFree(ctx->dirty);
-    if (ctx->sflags) (void)hipFree(ctx->sflags);
     if (ctx->tlist) (void)hipFree(ctx->tlist);
     if (ctx->dbg) (void)hipFree(ctx->dbg);
     if (ctx->det_ctl) (void)hipFree(ctx->det_ctl);
@@ -261,11 +247,6 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
         if (!t.tube) HIP_TRY(ctx, hipMalloc(&t.tube, tb.size() * 4));
         t.tube_bytes = tb.size() * 4;
         HIP_TRY(ctx, hipMemcpy(t.tube, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
-        if (t.band) {
-            HIP_TRY(ctx, hipFree(t.band));
-            HIP_TRY(ctx, hipFree(t.bandx));
-            t.band = t.bandx = nullptr;
-        }
     } else if (u == 2) {
         // tube band of a u == 2 table: 8 bytes per slot, (e0 | e1 << 16), (e2 | e3 << 16) as value + 128
         std::vector<uint32_t> tb((size_t)kTube2BandBytes / 4, 0x00800080u);
@@ -285,35 +266,9 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
         if (!t.tube) HIP_TRY(ctx, hipMalloc(&t.tube, tb.size() * 4));
         t.tube_bytes = tb.size() * 4;
         HIP_TRY(ctx, hipMemcpy(t.tube, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
-        if (t.band) {
-            HIP_TRY(ctx, hipFree(t.band));
-            HIP_TRY(ctx, hipFree(t.bandx));
-            t.band = t.bandx = nullptr;
-        }
     } else if (u == 4) {
-        // diagonal band (mulut_core.h): rows (A,B,C,D) with B-A, C-A, D-A in [-2,2], at band_slot()
-        std::vector<uint8_t> band((size_t)kBandRows * 16, 128);
-        for (int A = 0; A < kL; ++A)
-            for (int B = imax(0, A - 2); B <= imin(kL - 1, A + 2); ++B)
-                for (int C = imax(0, A - 2); C <= imin(kL - 1, A + 2); ++C)
-                    for (int D = imax(0, A - 2); D <= imin(kL - 1, A + 2); ++D) {
-                        const size_t full = (size_t)A * kStrideA + B * kStrideB + C * kStrideC + D;
-                        memcpy(&band[(size_t)band_slot(A, B, C, D) * 16], &img[full * 16], 16);
-                    }
-        if (!t.band) HIP_TRY(ctx, hipMalloc(&t.band, band.size()));
-        HIP_TRY(ctx, hipMemcpy(t.band, band.data(), band.size(), hipMemcpyHostToDevice));
-        // expanded: LO plane (lo_k = e(4k) | e(4k+2) << 16) then HI plane (hi_k = e(4k+1) | e(4k+3) << 16),
-        // 16-byte rows at the compact band's offsets, each plane padded to whole 1-KiB LDS-DMA pieces
-        std::vector<uint32_t> bx((size_t)2 * kBandXPlaneBytes / 4, 0u);
-        for (int r = 0; r < kBandRows; ++r)
-            for (int k = 0; k < 4; ++k) {
-                const uint8_t *e = &band[(size_t)r * 16 + 4 * k];
-                bx[(size_t)r * 4 + k] = (uint32_t)e[0] | ((uint32_t)e[2] << 16);
-                bx[(size_t)kBandXPlaneBytes / 4 + (size_t)r * 4 + k] = (uint32_t)e[1] | ((uint32_t)e[3] << 16);
-            }
-        if (!t.bandx) HIP_TRY(ctx, hipMalloc(&t.bandx, bx.size() * 4));
-        HIP_TRY(ctx, hipMemcpy(t.bandx, bx.data(), bx.size() * 4, hipMemcpyHostToDevice));
-        // tube band: rows with max - min of the keys <= 2 at tube_slot(), same two-plane expansion
+        // tube band: rows with max - min of the keys <= 2 at tube_slot(), expanded to 16-bit fields in two planes: LO (lo_k = e(4k) | e(4k+2) << 16)
+        // then HI (hi_k = e(4k+1) | e(4k+3) << 16)
         std::vector<uint32_t> tb((size_t)kTubeBandBytes / 4, 0x00800080u);
         for (int A = 0; A < kL; ++A)
             for (int B = imax(0, A - 2); B <= imin(kL - 1, A + 2); ++B)
@@ -343,11 +298,9 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
         if (!t.slab) HIP_TRY(ctx, hipMalloc((void **)&t.slab, sl.size()));
         HIP_TRY(ctx, hipMemcpy(t.slab, sl.data(), sl.size(), hipMemcpyHostToDevice));
     } else {
-        if (t.band) HIP_TRY(ctx, hipFree(t.band));
-        if (t.bandx) HIP_TRY(ctx, hipFree(t.bandx));
         if (t.tube) HIP_TRY(ctx, hipFree(t.tube));
         if (t.slab) HIP_TRY(ctx, hipFree(t.slab));
-        t.band = t.bandx = t.tube = nullptr;
+        t.tube = nullptr;
         t.slab = nullptr;
         t.tube_bytes = 0;
     }
@@ -426,7 +379,6 @@ static View make_view(const uint8_t *p, int layout, int rows, int W, int C, int 
 static int ensure_verdict(mulut_ctx *ctx, size_t tiles);
 static int ensure_fix(mulut_ctx *ctx, size_t ids);
 static int ensure_tlist(mulut_ctx *ctx, size_t tiles);
-static int ensure_sflags(mulut_ctx *ctx, size_t bytes);
 static int ensure_detail(mulut_ctx *ctx, size_t tiles, size_t items, size_t ids, size_t blocks);
 
 static hipError_t tube_launch(mulut_ctx *ctx, const StageArgs &a, const BandArgs &b, int mode, hipStream_t st) {
@@ -460,13 +412,13 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.use_f32 = ctx->f32_ok[last ? 1 : 0];
     a.epi_c = last ? ctx->epi_c : 127.0f;
     a.use_fma = last ? ctx->fma_ok : ctx->fma1_ok;
-    const bool band = u == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1;
-    const bool hybrid = band && (ctx->final_kernel == 0 || ctx->final_kernel == 4 || ctx->final_kernel == 6);
-    const bool tube = ctx->final_kernel == 0 || ctx->final_kernel == 5 || ctx->final_kernel == 6;
+    // u == 4, <= 3 modes: the LDS kernels (tube bands resident); final_kernel 5 = on every tile, 0 / 6 = hybrid with the per-tile statistic
+    const bool tube = u == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1;
+    const bool hybrid = tube && ctx->final_kernel != 5;
     a.verdict = nullptr;
     a.verdict_take = -1;
     int tw, th;
-    if (u == 1) stage_u1_tile(tw, th); else if (band) stage_band_tile(tw, th); else stage_up_tile(tw, th);
+    if (u == 1) stage_u1_tile(tw, th); else if (tube) stage_band_tile(tw, th); else stage_up_tile(tw, th);
     a.tiles_x = (W + tw - 1) / tw;
     a.tiles_y = (oy1 - oy0 + th - 1) / th;
     if (u == 1 && last) a.use_fma = 0;     // (a final stage with 1-byte rows -- scale 1 -- takes the integer epilogue)
@@ -478,7 +430,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         const bool tube1 = (ctx->first_kernel == 0 || ctx->first_kernel == 3) && ctx->n_modes <= 3 &&
                            (unsigned long long)N * C * H * W < (1ull << 32);
         if (!tube1) {
-            MAIN_KERNEL(ctx, stage, st, launch_stage_u1(a, st, ctx->first_kernel == 1 ? 1 : 0));
+            MAIN_KERNEL(ctx, stage, st, launch_stage_u1(a, st, 0));
             return MULUT_OK;
         }
         // tube kernel on the smooth tiles; the sites it flags are recomputed from the full tables, the tiles it leaves go
@@ -524,81 +476,55 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         MAIN_KERNEL(ctx, stage, st, launch_stage_u2t(a, b2, ctx->num_cus, st));
         return MULUT_OK;
     }
-    if (!band) {
+    if (!tube) {
         if (u == 4 && ctx->n_modes > 4) MAIN_KERNEL(ctx, stage, st, launch_stage_up_wide4(a, st));   // merged 16-bit fields hold 4 modes at most
         else MAIN_KERNEL(ctx, stage, st, launch_stage_up(a, u, mode, st));
         return MULUT_OK;
     }
-    const bool x = ctx->final_kernel != 2;   // compact band only on request
-    if (tube) {
-        // every sample of the launch may end up on the fix-up list (entries: 30-bit pixel id + channel)
-        if ((unsigned long long)N * H * W >= (1ull << 30)) return MULUT_EUNSUPPORTED;
-        rc = ensure_fix(ctx, (size_t)N * (oy1 - oy0) * W * 3);
-        if (rc) return rc;
-        a.fix_count = ctx->fix;
-        a.fix_list = ctx->fix + 16;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->fix, 0, sizeof(uint32_t), st));
-        if (ctx->site_flags_on) {
-            rc = ensure_sflags(ctx, (size_t)N * H * W);
-            if (rc) return rc;
-        }
-    }
+    // every sample of the launch may end up on the fix-up list (entries: 30-bit pixel id + channel)
+    if ((unsigned long long)N * H * W >= (1ull << 30)) return MULUT_EUNSUPPORTED;
+    rc = ensure_fix(ctx, (size_t)N * (oy1 - oy0) * W * 3);
+    if (rc) return rc;
+    a.fix_count = ctx->fix;
+    a.fix_list = ctx->fix + 16;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->fix, 0, sizeof(uint32_t), st));
     BandArgs b;
-    for (int m = 0; m < ctx->n_modes; ++m) {
-        const DevTable &t = ctx->tab[stage - 1][pattern_id(ctx->modes[m])];
-        b.band[m] = tube ? t.tube : x ? t.bandx : t.band;
+    for (int m = 0; m < ctx->n_modes; ++m) b.band[m] = ctx->tab[stage - 1][pattern_id(ctx->modes[m])].tube;
+    if (!hybrid) {
+        MAIN_KERNEL(ctx, stage, st, tube_launch(ctx, a, b, mode, st));
+        HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st, ctx->fix_variant));
+        return MULUT_OK;
     }
-    if (hybrid) {
-        // per-tile choice on the device: smooth tiles -> LDS band kernel, detailed tiles -> full-table kernel
-        rc = ensure_verdict(ctx, (size_t)N * a.tiles_x * a.tiles_y);
+    // per-tile choice on the device: smooth tiles -> tube kernel, detailed tiles -> anchor slabs in LDS (samples grouped by anchor
+    // MSB), or the full-table gather kernel where that path does not apply
+    rc = ensure_verdict(ctx, (size_t)N * a.tiles_x * a.tiles_y);
+    if (rc) return rc;
+    const bool slab = ctx->detail_kernel == 0 && detail_slab_supported(a);
+    if (slab) {
+        rc = ensure_detail(ctx, (size_t)N * a.tiles_x * a.tiles_y, detail_items_max(a), detail_ids_count(a), detail_blocks_count(a));
         if (rc) return rc;
-        // detailed tiles: samples grouped by anchor MSB, rows from the anchor's slab pair in LDS (else: the full-table gather kernel)
-        const bool slab = tube && !ctx->site_flags_on && ctx->detail_kernel == 0 && detail_slab_supported(a);
-        if (slab) {
-            rc = ensure_detail(ctx, (size_t)N * a.tiles_x * a.tiles_y, detail_items_max(a), detail_ids_count(a), detail_blocks_count(a));
-            if (rc) return rc;
-        }
-        if (tube && ctx->site_flags_on) {
-            HIP_TRY(ctx, launch_site_flags(a, ctx->verdict, ctx->sflags, (uint32_t)ctx->hybrid_oob_per_1024, st));
-            a.site_flags = ctx->sflags;
-        } else {
-            if (ctx->stat_from_k1 && k1_marks) {
-                a.k1_hdr = ctx->tlist;
-                a.k1_tiles_x = ctx->k1_tiles_x; a.k1_tiles_y = ctx->k1_tiles_y; a.k1_oy0 = ctx->k1_oy0;
-            }
-            // the control words of the detailed-tile path are cleared before the statistic: it raises ctl[kDetAny] when it marks a tile
-            if (slab && !ctx->dirty_to_slab) HIP_TRY(ctx, hipMemsetAsync(ctx->det_ctl, 0, kDetCtlDwords * sizeof(uint32_t), st));
-            HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st, slab ? ctx->det_thist : nullptr,
-                                          (slab && !ctx->dirty_to_slab) ? ctx->det_ctl + kDetAny : nullptr));
-            a.k1_hdr = nullptr;
-        }
-        a.verdict = ctx->verdict;
-        a.vt_x = a.tiles_x;
-        a.vt_y = a.tiles_y;
-        a.verdict_take = 0;
-        if (tube && slab && ctx->dirty_to_slab && !ctx->dirty) HIP_TRY(ctx, hipMalloc((void **)&ctx->dirty, (ctx->fix_cap + 16) * sizeof(uint32_t)));
-        if (tube && slab && ctx->dirty_to_slab) {
-            // the tube kernel's dirty samples go on their own list: the anchor-slab kernels compute them with the detailed tiles
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dirty, 0, sizeof(uint32_t), st));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->det_ctl, 0, kDetCtlDwords * sizeof(uint32_t), st));
-            StageArgs t = a;
-            t.fix_count = ctx->dirty;
-            t.fix_list = ctx->dirty + 16;
-            MAIN_KERNEL(ctx, stage, st, tube_launch(ctx, t, b, mode, st));
-        } else if (tube) MAIN_KERNEL(ctx, stage, st, tube_launch(ctx, a, b, mode, st));
-        else MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
-        if (slab) {
-            DetailArgs d;
-            memset(&d, 0, sizeof(d));
-            d.ctl = ctx->det_ctl; d.items = ctx->det_items; d.desc = ctx->det_desc; d.blocks = ctx->det_blocks;
-            d.thist = ctx->det_thist; d.tpos = ctx->det_tpos; d.dlist = ctx->det_dlist;
-            if (ctx->dirty_to_slab) { d.dirty_count = ctx->dirty; d.dirty_list = ctx->dirty + 16; }
-
-            for (int m = 0; m < 3; ++m) d.slab[m] = m < ctx->n_modes ? ctx->tab[stage - 1][pattern_id(ctx->modes[m])].slab : nullptr;
-            HIP_TRY(ctx, launch_detail_slab(a, d, mode, ctx->num_cus, st));
-            HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st, ctx->fix_variant));
-            return MULUT_OK;
-        }
+        // the control words of the detailed-tile path are cleared before the statistic: it raises ctl[kDetAny] when it marks a tile
+        HIP_TRY(ctx, hipMemsetAsync(ctx->det_ctl, 0, kDetCtlDwords * sizeof(uint32_t), st));
+    }
+    if (ctx->stat_from_k1 && k1_marks) {
+        a.k1_hdr = ctx->tlist;
+        a.k1_tiles_x = ctx->k1_tiles_x; a.k1_tiles_y = ctx->k1_tiles_y; a.k1_oy0 = ctx->k1_oy0;
+    }
+    HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st, slab ? ctx->det_thist : nullptr, slab ? ctx->det_ctl + kDetAny : nullptr));
+    a.k1_hdr = nullptr;
+    a.verdict = ctx->verdict;
+    a.vt_x = a.tiles_x;
+    a.vt_y = a.tiles_y;
+    a.verdict_take = 0;
+    MAIN_KERNEL(ctx, stage, st, tube_launch(ctx, a, b, mode, st));
+    if (slab) {
+        DetailArgs d;
+        memset(&d, 0, sizeof(d));
+        d.ctl = ctx->det_ctl; d.items = ctx->det_items; d.desc = ctx->det_desc; d.blocks = ctx->det_blocks;
+        d.thist = ctx->det_thist; d.tpos = ctx->det_tpos; d.dlist = ctx->det_dlist;
+        for (int m = 0; m < 3; ++m) d.slab[m] = m < ctx->n_modes ? ctx->tab[stage - 1][pattern_id(ctx->modes[m])].slab : nullptr;
+        HIP_TRY(ctx, launch_detail_slab(a, d, mode, ctx->num_cus, st));
+    } else {
         StageArgs g = a;
         int gw, gh;
         stage_up_tile(gw, gh);
@@ -606,18 +532,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         g.tiles_y = (oy1 - oy0 + gh - 1) / gh;
         g.verdict_take = 1;
         HIP_TRY(ctx, launch_stage_up(g, u, mode, st));
-        if (tube) HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st, ctx->fix_variant));
-        return MULUT_OK;
     }
-    if (tube) {
-        if (ctx->site_flags_on) {
-            HIP_TRY(ctx, launch_site_flags(a, nullptr, ctx->sflags, 0u, st));
-            a.site_flags = ctx->sflags;
-        }
-        MAIN_KERNEL(ctx, stage, st, tube_launch(ctx, a, b, mode, st));
-        HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st, ctx->fix_variant));
-    } else if (x) MAIN_KERNEL(ctx, stage, st, launch_stage_bandx(a, b, mode, ctx->num_cus, st));
-    else MAIN_KERNEL(ctx, stage, st, launch_stage_band(a, b, mode, ctx->num_cus, st));
+    HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st, ctx->fix_variant));
     return MULUT_OK;
 }
 
@@ -638,21 +554,10 @@ static int ensure_workspace(mulut_ctx *ctx, size_t bytes) {
 static int ensure_fix(mulut_ctx *ctx, size_t ids) {
     if (ids <= ctx->fix_cap) return MULUT_OK;
     if (ctx->fix) HIP_TRY(ctx, hipFree(ctx->fix));
-    if (ctx->dirty) HIP_TRY(ctx, hipFree(ctx->dirty));      // (sized like fix; reallocated on demand by the dirty_to_slab option)
-    ctx->fix = ctx->dirty = nullptr;
+    ctx->fix = nullptr;
     ctx->fix_cap = 0;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->fix, (ids + 16) * sizeof(uint32_t)));
     ctx->fix_cap = ids;
-    return MULUT_OK;
-}
-
-static int ensure_sflags(mulut_ctx *ctx, size_t bytes) {
-    if (bytes <= ctx->sflags_cap) return MULUT_OK;
-    if (ctx->sflags) HIP_TRY(ctx, hipFree(ctx->sflags));
-    ctx->sflags = nullptr;
-    ctx->sflags_cap = 0;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->sflags, bytes));
-    ctx->sflags_cap = bytes;
     return MULUT_OK;
 }
 
@@ -731,8 +636,6 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
             rc = ensure_fix(ctx, (size_t)N * H * W * ((u1 || ctx->scale == 2 || ctx->scale == 4) ? (size_t)(C > 3 ? C : 3) : 1));
             if (rc) return rc;
             if (ctx->scale == 4) {
-                rc = ensure_sflags(ctx, (size_t)N * H * W);
-                if (rc) return rc;
                 stage_band_tile(tw, th);
                 StageArgs t;
                 memset(&t, 0, sizeof(t));
@@ -887,12 +790,12 @@ int mulut_debug_read(mulut_ctx *ctx, unsigned long long *out, int cap, int reset
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return MULUT_EINVAL;
     if (!strcmp(key, "final_stage_kernel")) {
-        if (value < 0 || value > 6) return MULUT_EINVAL;
+        if (value != 0 && value != 1 && value != 5 && value != 6) return MULUT_EINVAL;      // (2-4: generations retired in round 3)
         ctx->final_kernel = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "first_stage_kernel")) {
-        if (value < 0 || value > 3) return MULUT_EINVAL;
+        if (value != 0 && value != 2 && value != 3) return MULUT_EINVAL;      // (1: retired in round 3)
         ctx->first_kernel = value;
         return MULUT_OK;
     }
@@ -911,19 +814,9 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
         ctx->tube2 = value;
         return MULUT_OK;
     }
-    if (!strcmp(key, "dirty_to_slab")) {
-        if (value < 0 || value > 1) return MULUT_EINVAL;
-        ctx->dirty_to_slab = value;
-        return MULUT_OK;
-    }
     if (!strcmp(key, "detail_kernel")) {     // final-stage tiles the statistic marks detailed: 0 anchor slabs in LDS, 1 full-table gathers
         if (value < 0 || value > 1) return MULUT_EINVAL;
         ctx->detail_kernel = value;
-        return MULUT_OK;
-    }
-    if (!strcmp(key, "tube_site_flags")) {
-        if (value < 0 || value > 1) return MULUT_EINVAL;
-        ctx->site_flags_on = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "u1t_persist")) {      // experiment: persistent workgroups per CU of the 1-byte-row tube kernel (0 = one per tile)
@@ -948,15 +841,15 @@ const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (!ctx || !ctx->configured) return "";
     if (!is_final || ctx->scale == 1) return stage_u1_name(ctx->first_kernel);
     if (ctx->scale == 2 && ctx->n_modes <= 3 && ctx->final_kernel != 1) return "stage_u1t_kernel<2> + stage_up_fix_site_kernel<2>";
-    if (ctx->scale == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1)
-        return ctx->final_kernel == 2 ? stage_band_name(kOutPackedRGBU4)
-               : ctx->final_kernel == 3 ? stage_bandx_name(kOutPackedRGBU4)
-               : ctx->final_kernel == 5 ? stage_tube_name(kOutPackedRGBU4)
-               : ((ctx->final_kernel == 6 || ctx->final_kernel == 0) && ctx->tube2 && ctx->detail_kernel == 0 && !ctx->site_flags_on && !strcmp(ctx->modes, "sdy"))
-                   ? "hybrid: tile_stat_kernel + stage_tube2_kernel<rgb> (smooth tiles; hand-scheduled LDS pipeline, one 16x4 tile per wave) + stage_slab_kernel (detailed tiles, anchor slabs in LDS)"
-               : (ctx->final_kernel == 6 || ctx->final_kernel == 0) ? (ctx->detail_kernel == 0 ? "hybrid: tile_stat_kernel + stage_tube_kernel<rgb> (smooth tiles) + stage_slab_kernel (detailed tiles, anchor slabs in LDS)"
-                                           : "hybrid: tile_stat_kernel + stage_tube_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)")
-                                        : "hybrid: tile_stat_kernel + stage_bandx_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)";
+    if (ctx->scale == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1) {
+        const bool t2 = ctx->tube2 && !strcmp(ctx->modes, "sdy");
+        if (ctx->final_kernel == 5) return t2 ? "stage_tube2_kernel<rgb> + stage_up_fix2_kernel" : "stage_tube_kernel<rgb> + stage_up_fix2_kernel";
+        if (ctx->detail_kernel == 0)
+            return t2 ? "hybrid: tile_stat_kernel + stage_tube2_kernel<rgb> (smooth tiles; hand-scheduled LDS pipeline, one 16x4 tile per wave) + stage_slab_kernel (detailed tiles, anchor slabs in LDS)"
+                      : "hybrid: tile_stat_kernel + stage_tube_kernel<rgb> (smooth tiles) + stage_slab_kernel (detailed tiles, anchor slabs in LDS)";
+        return t2 ? "hybrid: tile_stat_kernel + stage_tube2_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)"
+                  : "hybrid: tile_stat_kernel + stage_tube_kernel<rgb> (smooth tiles) + stage_up_kernel<4,rgb> (detailed tiles)";
+    }
     return stage_up_name(ctx->scale, ctx->scale == 4 ? kOutPackedRGBU4 : kOutGeneric);
 }
 

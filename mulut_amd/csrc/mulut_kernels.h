@@ -57,8 +57,7 @@ struct StageArgs {
     // stage_up_fix_kernel; *fix_count is zeroed by the host side before the stage
     uint32_t *fix_list;
     uint32_t *fix_count;
-    // per-pixel flag bytes written by site_flag_kernel ahead of the tube kernel (null: the tube kernel tests every pass itself)
-    const uint8_t *site_flags;
+    const uint8_t *site_flags;     // (always null: the per-pixel flag pass was retired in round 3; the tube kernels test every pass themselves)
     // 1-byte-row tube kernel: tile_list[tile] = 1 for the tiles it leaves to the full-table kernel (stage_u1w_kernel in
     // list mode); zeroed by the host side before the stage
     uint32_t *tile_list;
@@ -74,11 +73,8 @@ struct PassArgs {
     signed char di[3], dj[3];
 };
 
-// expanded band image: LO plane then HI plane, each kBandXPlaneBytes (16-byte rows, padded to 1 KiB)
-constexpr int kBandXPlaneBytes = ((kBandRows * 16 + 1023) / 1024) * 1024;
-
 struct BandArgs {
-    const void *band[3];   // device images of the diagonal band of each mode's table (kBandRows x 16 B)
+    const void *band[3];   // device images of the tube band of each mode's table (mulut_core.h: kTubeBandBytes / kTube2BandBytes / kTube1BandBytes)
 };
 
 enum K2Out { kOutGeneric = 0, kOutPlanarU4 = 1, kOutPackedRGBU4 = 2 };
@@ -124,12 +120,7 @@ extern int g_u1t_persist;
 hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t st);
 // u == 4 and more than four modes (per-rotation accumulators)
 hipError_t launch_stage_up_wide4(const StageArgs &a, hipStream_t st);
-// final stage, u == 4, M <= 3: band tables resident in LDS, persistent workgroups
-hipError_t launch_stage_band(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
-// same, with the band rows expanded to 16-bit fields in LDS (one mode resident, mode loop outermost)
-hipError_t launch_stage_bandx(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
-const char *stage_bandx_name(int out_mode);
-// same, with the "tube" bands (mulut_core.h) of all modes resident together: b.band[m] = expanded tube image of
+// final stage, u == 4, M <= 3, with the "tube" bands (mulut_core.h) of all modes resident in LDS: b.band[m] = expanded tube image of
 // mode m (LO plane then HI plane, kTubeBandBytes); no band swaps, channel-outer loops
 hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 const char *stage_tube_name(int out_mode);
@@ -151,10 +142,7 @@ hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_m
 // any (optional): set to 1 when some tile is marked detailed (DetailArgs::ctl + kDetAny, zeroed by the caller BEFORE this launch): the
 // kernels of the detailed-tile path leave at once while it is 0
 hipError_t launch_tile_stat(const StageArgs &a, uint32_t *verdict, uint32_t max_oob_per_1024, hipStream_t st, uint16_t *thist = nullptr, uint32_t *any = nullptr);
-// per-pixel tube flags (bit c: channel c's 5x5 neighbourhood spans > 1 MSB step) + the same per-tile verdict from them
-hipError_t launch_site_flags(const StageArgs &a, uint32_t *verdict, uint8_t *flags, uint32_t max_per_1024, hipStream_t st);
 void stage_band_tile(int &tw, int &th);
-const char *stage_band_name(int out_mode);
 void stage_u1_tile(int &tw, int &th);
 void stage_up_tile(int &tw, int &th);
 const char *stage_u1_name(int variant);

@@ -327,7 +327,7 @@ def test_pipeline_replays_from_a_captured_graph():
 
 
 def test_hybrid_final_stage_variants_agree_and_capture(eng, shipped_luts):
-    """Every final-stage variant (full-table, compact band, expanded band, hybrid with several thresholds) gives
+    """Every final-stage variant (full-table gathers, both tube kernels on every tile, hybrid with several thresholds) gives
     the same bytes on smooth, photographic and noisy content; the default (hybrid) path replays from a hipGraph."""
     from mulut_amd.synth import natural_frames, noise_frames, real_frames
     png = os.path.join(GOLDEN, "DIV2K_LR_X4", "0001x4.png")
@@ -337,20 +337,25 @@ def test_hybrid_final_stage_variants_agree_and_capture(eng, shipped_luts):
     eng.set_tuning("final_stage_kernel", 1)
     want = eng.pipeline(x).clone()
     assert np.array_equal(want[2].cpu().numpy(), c_oracle.pipeline(shipped_luts, 2, "sdy", 4, frames[2]))
-    for sel, thr in ((2, None), (3, None), (4, 0), (4, 128), (4, 1024), (5, None), (6, 0), (6, 128), (6, 1024), (0, None)):
-        eng.set_tuning("final_stage_kernel", sel)
-        if thr is not None:
-            eng.set_tuning("hybrid_oob_per_1024", thr)
-        assert torch.equal(eng.pipeline(x), want), (sel, thr)
-    eng.set_tuning("hybrid_oob_per_1024", 128).set_tuning("final_stage_kernel", 0)
-    for key in ("stat_from_first_stage", "dirty_to_slab", "detail_kernel"):       # the routing / work-list options of the default path
+    for pipelined in (1, 0):          # stage_tube2_kernel (hand-scheduled, the default for sdy) and stage_tube_kernel (any mode list)
+        eng.set_tuning("tube_pipelined", pipelined)
+        for sel, thr in ((5, None), (6, 0), (6, 128), (6, 1024), (0, None)):
+            eng.set_tuning("final_stage_kernel", sel)
+            if thr is not None:
+                eng.set_tuning("hybrid_oob_per_1024", thr)
+            assert torch.equal(eng.pipeline(x), want), (pipelined, sel, thr)
+    eng.set_tuning("tube_pipelined", 1).set_tuning("hybrid_oob_per_1024", 128).set_tuning("final_stage_kernel", 0)
+    for key in ("stat_from_first_stage", "detail_kernel", "fix_kernel"):       # the routing / work-list options of the default path
         for val in (0, 1):
             eng.set_tuning(key, val)
             assert torch.equal(eng.pipeline(x), want), (key, val)
-    eng.set_tuning("stat_from_first_stage", 1).set_tuning("dirty_to_slab", 0).set_tuning("detail_kernel", 0)
-    eng.set_tuning("first_stage_kernel", 1)                 # first stage: one-read-per-neighbour kernel == window kernel
-    assert torch.equal(eng.pipeline(x), want)
-    eng.set_tuning("first_stage_kernel", 0)
+    eng.set_tuning("stat_from_first_stage", 1).set_tuning("detail_kernel", 0).set_tuning("fix_kernel", 0)
+    for first in (2, 3, 0):                 # first stage: window kernel everywhere, tube kernel everywhere, the routed default
+        eng.set_tuning("first_stage_kernel", first)
+        assert torch.equal(eng.pipeline(x), want), first
+    for retired in (("final_stage_kernel", 3), ("first_stage_kernel", 1), ("tube_site_flags", 1)):      # generations moved out in round 3
+        with pytest.raises(Exception):
+            eng.set_tuning(*retired)
     # capture the default path
     out = torch.empty_like(want)
     eng.reserve(3, 150, 200, 3)

@@ -17,16 +17,16 @@ for (h, w) in ((150, 200), (37, 129), (270, 480)):
     x = torch.from_numpy(fr).cuda()
     e.set_tuning("final_stage_kernel", 1)
     want = e.pipeline(x).clone()
-    e.set_tuning("first_stage_kernel", 1)
+    e.set_tuning("first_stage_kernel", 2)
     want = e.pipeline(x).clone()
-    for first in (0, 1, 2, 3):
-        for sel in (2, 3, 4, 5, 6):
-            for det in ((0, 1) if sel == 6 else (0,)):      # detailed tiles of the hybrid: anchor slabs / full-table gathers
-                e.set_tuning("final_stage_kernel", sel).set_tuning("first_stage_kernel", first).set_tuning("detail_kernel", det)
+    for first in (0, 2, 3):
+        for sel in (5, 6):
+            for det, t2 in (((0, 1), (1, 1), (0, 0)) if sel == 6 else ((0, 1), (0, 0))):      # detailed tiles of the hybrid: anchor slabs / full-table gathers; tube2 / tube
+                e.set_tuning("final_stage_kernel", sel).set_tuning("first_stage_kernel", first).set_tuning("detail_kernel", det).set_tuning("tube_pipelined", t2)
                 got = e.pipeline(x)
                 same = torch.equal(got, want)
                 ok &= same
                 bad = (got != want)
                 where = "" if same else " first at %s" % (tuple(int(v) for v in bad.nonzero()[0]),)
-                print(h, w, "first", first, "final", sel, "detail", det, "OK" if same else "MISMATCH %d%s" % (int(bad.sum()), where))
+                print(h, w, "first", first, "final", sel, "detail", det, "pipelined", t2, "OK" if same else "MISMATCH %d%s" % (int(bad.sum()), where))
 sys.exit(0 if ok else 1)

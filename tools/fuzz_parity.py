@@ -63,12 +63,12 @@ def main():
                 else:
                     luts["s%d_%s" % (s + 1, m)] = synthetic_lut(int(rng.integers(1 << 30)), vn)
         e = MuLUTEngine(0).configure(stages, modes, scale, 4).set_lut_dict(luts)
-        e.set_tuning("final_stage_kernel", int(rng.integers(0, 7)))
+        e.set_tuning("final_stage_kernel", int(rng.choice([0, 1, 5, 6])))
+        e.set_tuning("tube_pipelined", int(rng.integers(0, 4) != 0))      # mostly the hand-scheduled kernel (the default)
+        e.set_tuning("fix_kernel", int(rng.integers(0, 4) == 0))
         e.set_tuning("hybrid_oob_per_1024", int(rng.choice([0, 16, 128, 512, 1024])))
-        e.set_tuning("first_stage_kernel", int(rng.integers(0, 4)))
-        e.set_tuning("tube_site_flags", int(rng.integers(0, 2)))
+        e.set_tuning("first_stage_kernel", int(rng.choice([0, 2, 3])))
         e.set_tuning("detail_kernel", int(rng.integers(0, 4) == 0))      # mostly the anchor-slab kernel (the default)
-        e.set_tuning("dirty_to_slab", int(rng.integers(0, 3) == 0))      # an option (default off)
         e.set_tuning("stat_from_first_stage", int(rng.integers(0, 4) != 0))      # mostly on (the default)
         e.set_tuning("first_stage_detail_per_1024", int(rng.choice([0, 64, 256, 1024])))
         n = int(rng.integers(1, 4))
