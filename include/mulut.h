@@ -179,8 +179,8 @@ int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int
  * hipGraph capture: call mulut_reserve() for the largest (N, H, W, C) first -- the context's workspace, verdict and work-list
  * buffers are then never reallocated by smaller calls; a LARGER later call reallocates them and invalidates graphs captured
  * before it.  Run the call to be captured once outside capture first: the first launch of each kernel raises that kernel's
- * dynamic-LDS limit (hipFuncSetAttribute), which is not a capturable operation.  These one-time per-device set-ups are not
- * synchronised between host threads: issue the first call of a process from one thread. */
+ * dynamic-LDS limit (hipFuncSetAttribute), which is not a capturable operation.  These one-time per-device set-ups are
+ * serialised inside the library: contexts may be created and first used from several host threads. */
 int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value);
 
 /* Name of the kernel variant used for the final / non-final stage (for profiles). */

@@ -387,8 +387,10 @@ static hipError_t tube_launch(mulut_ctx *ctx, const StageArgs &a, const BandArgs
 }
 
 // Launch one stage: input view holds LR rows [in.row0, ...), outputs for LR rows [oy0, oy1).
+// C channels are processed (<= 3); they may be a group of an image with more (then the views carry that image's strides and
+// packed_ok is false: the packed-RGB store needs a pixel stride of exactly 3)
 static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
-                     int C, int oy0, int oy1, hipStream_t st) {
+                     int C, int oy0, int oy1, hipStream_t st, bool packed_ok = true) {
     StageArgs a;
     memset(&a, 0, sizeof(a));
     int rc = stage_tables(ctx, stage, a.lut);
@@ -458,8 +460,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         return MULUT_OK;
     }
     int mode = kOutGeneric;
-    if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || C == 1)) mode = kOutPlanarU4;
-    else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3) mode = kOutPackedRGBU4;
+    if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || (C == 1 && packed_ok))) mode = kOutPlanarU4;
+    else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3 && packed_ok) mode = kOutPackedRGBU4;
     if (u == 2 && ctx->n_modes <= 3 && ctx->final_kernel != 1 && (unsigned long long)N * C * H * W < (1ull << 32)) {
         // u == 2 final stage on the tube band (the 1-byte-row kernel family with 4-value rows); flagged sites recomputed from the full table
         rc = ensure_fix(ctx, (size_t)N * C * (oy1 - oy0) * W);
@@ -660,19 +662,26 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
 
 int mulut_stage(mulut_ctx *ctx, int stage, const uint8_t *in, int in_layout, uint8_t *out, int out_layout, int N,
                 int H, int W, int C, void *stream) {
-    if (!ctx || !in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 3) return MULUT_EINVAL;
+    if (!ctx || !in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MULUT_EINVAL;
     if (!ctx->configured) return MULUT_ENOTCONFIGURED;
     if (stage < 1 || stage > ctx->stages) return MULUT_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int u = stage_u(ctx, stage);
-    const View vin = make_view(in, in_layout, H, W, C, 0);
-    const View vout = make_view(out, out_layout, H * u, W * u, C, 0);
-    return run_stage(ctx, stage, vin, vout, out_layout, N, H, W, C, 0, H, (hipStream_t)stream);
+    // channels are independent planes through the same tables (sr/4_test_lut.py:14-237 is channel-count agnostic): more than three
+    // run in groups of three, each group a view into the caller's buffers
+    for (int c0 = 0; c0 < C; c0 += 3) {
+        View vin = make_view(in, in_layout, H, W, C, 0), vout = make_view(out, out_layout, H * u, W * u, C, 0);
+        vin.p += (long long)c0 * vin.sC;
+        vout.p += (long long)c0 * vout.sC;
+        const int rc = run_stage(ctx, stage, vin, vout, out_layout, N, H, W, imin(3, C - c0), 0, H, (hipStream_t)stream, C <= 3);
+        if (rc) return rc;
+    }
+    return MULUT_OK;
 }
 
 int mulut_pipeline_rows(mulut_ctx *ctx, const uint8_t *in, int in_row0, int in_rows, uint8_t *out, int y0, int y1,
                         int N, int H, int W, int C, int layout, void *stream) {
-    if (!ctx || !in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 3) return MULUT_EINVAL;
+    if (!ctx || !in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MULUT_EINVAL;
     if (!ctx->configured) return MULUT_ENOTCONFIGURED;
     if (y0 < 0 || y1 > H || y0 >= y1 || in_row0 < 0 || in_rows <= 0 || in_row0 + in_rows > H) return MULUT_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -688,30 +697,37 @@ int mulut_pipeline_rows(mulut_ctx *ctx, const uint8_t *in, int in_row0, int in_r
     if (S > 1) {
         size_t need = 0;
         for (int s = 1; s < S; ++s) {
-            const size_t b = (size_t)N * C * (hi[s] - lo[s]) * W;
+            const size_t b = (size_t)N * imin(C, 3) * (hi[s] - lo[s]) * W;
             if (b > need) need = b;
         }
         int rc = ensure_workspace(ctx, need);
         if (rc) return rc;
     }
-    View cur = make_view(in, layout, in_rows, W, C, in_row0);
     ctx->timed_stages = 0;
-    if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], (hipStream_t)stream));
-    for (int s = 1; s <= S; ++s) {
-        const int u = stage_u(ctx, s);
-        View dst;
-        int dst_layout;
-        if (s == S) {
-            dst = make_view(out, layout, (y1 - y0) * u, W * u, C, y0 * u);
-            dst_layout = layout;
-        } else {
-            dst = make_view(ctx->ws[s & 1], MULUT_LAYOUT_CHW, hi[s] - lo[s], W, C, lo[s]);
-            dst_layout = MULUT_LAYOUT_CHW;
+    // channels are independent planes through the same tables (the reference function is channel-count agnostic): more than three
+    // run as groups of three, each a view into the caller's buffers (stage timing: the last group's)
+    for (int c0 = 0; c0 < C; c0 += 3) {
+        const int Cg = imin(3, C - c0);
+        View cur = make_view(in, layout, in_rows, W, C, in_row0);
+        cur.p += (long long)c0 * cur.sC;
+        if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], (hipStream_t)stream));
+        for (int s = 1; s <= S; ++s) {
+            const int u = stage_u(ctx, s);
+            View dst;
+            int dst_layout;
+            if (s == S) {
+                dst = make_view(out, layout, (y1 - y0) * u, W * u, C, y0 * u);
+                dst.p += (long long)c0 * dst.sC;
+                dst_layout = layout;
+            } else {
+                dst = make_view(ctx->ws[s & 1], MULUT_LAYOUT_CHW, hi[s] - lo[s], W, Cg, lo[s]);
+                dst_layout = MULUT_LAYOUT_CHW;
+            }
+            int rc = run_stage(ctx, s, cur, dst, dst_layout, N, H, W, Cg, lo[s], hi[s], (hipStream_t)stream, C <= 3);
+            if (rc) return rc;
+            if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[s], (hipStream_t)stream));
+            cur = dst;
         }
-        int rc = run_stage(ctx, s, cur, dst, dst_layout, N, H, W, C, lo[s], hi[s], (hipStream_t)stream);
-        if (rc) return rc;
-        if (ctx->timing) HIP_TRY(ctx, hipEventRecord(ctx->ev[s], (hipStream_t)stream));
-        cur = dst;
     }
     if (ctx->timing) ctx->timed_stages = S;
     return MULUT_OK;

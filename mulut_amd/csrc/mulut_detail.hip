@@ -517,13 +517,9 @@ size_t detail_blocks_count(const StageArgs &a) { return (size_t)a.N * (size_t)(a
 // the detailed tiles (a.verdict[tile] == 1, histograms in d.thist from launch_tile_stat) of a u == 4 final stage
 hipError_t launch_detail_slab(const StageArgs &a, const DetailArgs &d, int out_mode, int num_cus, hipStream_t st) {
     if (!detail_slab_supported(a) || !a.verdict || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)stage_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {
+        const hipError_t e = raise_lds_limit((const void *)stage_slab_kernel, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
     }
     const unsigned tiles = (unsigned)((long long)a.N * a.tiles_x * a.tiles_y);
     const unsigned walk = tiles < (unsigned)(8 * num_cus) ? tiles : (unsigned)(8 * num_cus);      // workgroups walking the list of detailed tiles

@@ -21,6 +21,7 @@
 
 #include "../../include/mulut.h"
 #include "mulut_core.h"
+#include "mulut_kernels.h"
 
 #pragma clang fp contract(off)
 
@@ -385,13 +386,9 @@ static hipError_t launch_ft(const FtArgs &a, bool backward, hipStream_t st) {
     const long long nb = (nsite + 255) / 256;
     if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
     if (backward && U == 4) {
-        static bool attr_set[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-        if (!attr_set[dev]) {
-            hipError_t e = hipFuncSetAttribute((const void *)ft_stage_bwd4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        {
+            const hipError_t e = mulut::raise_lds_limit((const void *)ft_stage_bwd4, 160 * 1024);
             if (e != hipSuccess) return e;
-            attr_set[dev] = true;
         }
         const long long nb4 = (nsite + kFtB4Sites - 1) / kFtB4Sites;
         hipLaunchKernelGGL(ft_stage_bwd4, dim3((unsigned)nb4), dim3(kFtB4Sites), (size_t)kFtB4Lds, st, a);

@@ -195,13 +195,9 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant) {
     if (a.C > 3) return hipErrorInvalidValue;
     auto kern = stage_u1w_kernel<K1_TW, K1_TH, K1_NT, false>;      // (variant: kept in the signature for the tuning knob; one kernel is left)
     const size_t lds = (size_t)kU1TableBytes + (size_t)a.C * (K1_TH + 2 * kHalo) * (K1_TW + 2 * kHalo);
-    static bool attr_set[64][2] = {};  // per device: >64 KB of dynamic LDS has to be opted into
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev][variant == 1]) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    {
+        const hipError_t e = raise_lds_limit((const void *)kern, 120 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev][variant == 1] = true;
     }
     const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;
     if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -662,13 +658,9 @@ int g_u1t_persist = 0;      // experiment knob (mulut_set_tuning "u1t_persist")
 
 template <int U>
 static hipError_t launch_u1t_t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st) {
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)stage_u1t_kernel<U>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    {
+        const hipError_t e = raise_lds_limit((const void *)stage_u1t_kernel<U>, 80 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
     }
     const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -689,13 +681,9 @@ hipError_t launch_stage_u1w_list(const StageArgs &a, int num_cus, hipStream_t st
     if (a.C > 3 || !a.tile_list || !a.tile_count) return hipErrorInvalidValue;
     auto kern = stage_u1w_kernel<K1_TW, K1_TH, K1_NT, true>;
     const size_t lds = (size_t)kU1TableBytes + (size_t)a.C * (K1_TH + 2 * kHalo) * (K1_TW + 2 * kHalo);
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    {
+        const hipError_t e = raise_lds_limit((const void *)kern, 120 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
     }
     const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
     const unsigned grid = (unsigned)(ntiles < num_cus ? ntiles : num_cus);

@@ -100,6 +100,10 @@ struct DetailArgs {
     const uint8_t *slab[3];    // per mode: the table as 16 slab pairs (mulut_core.h), kSlabTableBytes (+ 1 KiB of padding: the copy moves whole KiB)
 };
 
+// Raises a kernel's dynamic-LDS limit once per (device, kernel); safe to call from several host threads (engines may be created
+// and first used concurrently).  Not a capturable operation: the first launch of a kernel must happen outside hipGraph capture.
+hipError_t raise_lds_limit(const void *kernel, int bytes);
+
 hipError_t launch_pass(const PassArgs &a, hipStream_t st);
 // non-final (or u == 1 final) stage: tables staged in LDS, one byte out per site
 // variant 0: window kernel (four adjacent pixels per thread, neighbours from registers), 1: one site per LDS read

@@ -12,6 +12,10 @@
 // No MFMA: this is gather + lerp, bounded by LDS/L1 gather rate and VALU, not by a contraction.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "mulut_dev.h"
 
 namespace mulut {
@@ -60,6 +64,19 @@ __global__ void __launch_bounds__(256) pass_kernel(PassArgs a) {
                 po[(long long)(y * u + sy) * Wo + (x * u + sx)] = acc;
             }
     }
+}
+
+hipError_t raise_lds_limit(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({dev, kernel});
+    return e;
 }
 
 hipError_t launch_pass(const PassArgs &a, hipStream_t st) {
@@ -712,13 +729,9 @@ static hipError_t launch_tube_t(const StageArgs &a, const BandArgs &b, int num_c
     auto kern_t = stage_tube_kernel<OUT, KB_TW, KB_TH, true>;
     auto kern_f = stage_tube_kernel<OUT, KB_TW, KB_TH, false>;
     auto kern = a.site_flags ? kern_t : kern_f;
-    static bool attr_set[64][2] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev][a.site_flags ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {
+        const hipError_t e = raise_lds_limit((const void *)kern, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev][a.site_flags ? 1 : 0] = true;
     }
     const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -1145,13 +1158,9 @@ bool stage_tube2_supported(const StageArgs &a) {
 template <int OUT>
 static hipError_t launch_tube2_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
     auto kern = stage_tube2_kernel<OUT, kT2PatsSDY>;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {
+        const hipError_t e = raise_lds_limit((const void *)kern, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
     }
     const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;

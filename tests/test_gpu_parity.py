@@ -171,6 +171,17 @@ def test_shapes_vs_oracle(eng, shipped_luts, shape):
     assert np.array_equal(got, c_oracle.pipeline(shipped_luts, 2, "sdy", 4, img))
 
 
+@pytest.mark.parametrize("C", [4, 5, 7])
+def test_more_than_three_channels(eng, shipped_luts, C):
+    """The reference function is channel-count agnostic (sr/4_test_lut.py:14-237): the boundary runs groups of three planes."""
+    img = np.concatenate([natural_image(45, 70, 3, seed=C), np.random.default_rng(C).integers(0, 256, (45, 70, C - 3), dtype=np.uint8)], axis=2)
+    want = c_oracle.pipeline(shipped_luts, 2, "sdy", 4, img)
+    assert want.shape == (180, 280, C)
+    assert np.array_equal(eng.pipeline(dev(img)).cpu().numpy(), want)
+    got_p = eng.pipeline(dev(img.transpose(2, 0, 1)), layout=LAYOUT_CHW).cpu().numpy()
+    assert np.array_equal(got_p.transpose(1, 2, 0), want)
+
+
 def test_batch_and_natural_vs_oracle(eng, shipped_luts):
     imgs = np.stack([natural_image(70, 150, 3, seed=s) for s in range(3)] +
                     [np.random.default_rng(9).integers(0, 256, (70, 150, 3), dtype=np.uint8)])
