@@ -416,10 +416,17 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
         return t;
     };
 
+#if defined(MULUT_VARIANT_k1prof)   /* probe build: shader-clock ticks per phase, summed over all waves into the context's probe buffer (words 16..19) */
+    uint32_t t_prev = (uint32_t)__builtin_amdgcn_s_memtime(), t_ph0 = 0, t_ph1 = 0, t_ph2 = 0, t_ph3 = 0;
+#define K1_STAMP(PH) do { const uint32_t t_now = (uint32_t)__builtin_amdgcn_s_memtime(); t_ph##PH += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define K1_STAMP(PH) do { } while (0)
+#endif
     for (int tile = first; tile < last; tile += step) {
         int n, y0, x0;
         decode_tile(a, tile, n, y0, x0, TW, TH);
         __syncthreads();      // everyone is done with the previous tile (and, first trip, the bands are staged)
+        K1_STAMP(0);          // band staging (first trip), barrier
         if (threadIdx.x == 0) {
             uint32_t z = 0;
             asm volatile("" : "+v"(z));      // made here: the compiler otherwise keeps a zero pair live across the whole kernel -- in scratch
@@ -486,6 +493,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                 continue;
             }
         }
+        K1_STAMP(1);          // routing statistic (two barriers)
         // store one group of four pixel codes (two packed pairs) of channel c: image columns gx .. gx + 3 -> tile columns gx - x0 + 2 ...
         auto put4 = [&](int c, int row, int g, uint32_t c01, uint32_t c23) {
             uint32_t *dst = (uint32_t *)(s_tile + 2 * ((c * PH + row) * PW + 4 * g - 2));
@@ -515,6 +523,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
             }
         }
         __syncthreads();      // tile in place
+        K1_STAMP(2);          // tile load + barrier
 #pragma clang loop unroll(disable)
         for (int half = 0; half < TH * (TW / 4) / NT; ++half) {
         {
@@ -613,7 +622,15 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
             }
         }
         }
+        K1_STAMP(3);          // the sites
     }
+#if defined(MULUT_VARIANT_k1prof)
+    if (a.dbg && (threadIdx.x & 63) == 0) {
+        atomicAdd(a.dbg + 16, (unsigned long long)t_ph0); atomicAdd(a.dbg + 17, (unsigned long long)t_ph1);
+        atomicAdd(a.dbg + 18, (unsigned long long)t_ph2); atomicAdd(a.dbg + 19, (unsigned long long)t_ph3);
+    }
+#endif
+#undef K1_STAMP
 }
 
 // Fix-up of the 1-byte-row tube kernel: every listed site (id = ((n C + c) H + y) W + x) is recomputed from the full
