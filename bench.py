@@ -476,8 +476,10 @@ def config4(args, world, rank, local, timed, steps=None):
     el = timed(step, steps)
     ms = el / steps * 1e3
     # the backward kernel of the final stage dominates the step; two candidate bounds for it, both from MI355X_MICROARCH.md:
-    # LDS float adds into the tube band (ds_add_f32: one 4-byte lane group op per 2 LDS cycles per CU at best) and the memory-side
-    # float-atomic rate (about 1.3 TB/s of added bytes chip-wide) for the rows outside the band and the flush
+    # The table-gradient adds are LDS read + add + write of an address private to a 16-lane group (7.0 cycles of the CU's LDS
+    # pipeline per 64-lane wave instruction, measured: profiles/r03_ubench_lds_atomic.txt; a ds_add_f32 takes 48 whatever its
+    # addresses, which is why only evictions use it); rows outside the band and the flush use memory-side float atomics
+    # (about 1.3 TB/s of added bytes chip-wide)
     sites = bs * crop * crop
     adds = sites * 12 * 5 * 16                     # (site, pass, row, element) float adds into the final-stage tables
     counters = load_profile_json("finetune_counters.json")
@@ -488,11 +490,11 @@ def config4(args, world, rank, local, timed, steps=None):
         "config": {"workload": "config 4: bs 256 x 1x48x48 crops of the D-natural field per GPU per step, shipped tables as the start point",
                    "note": "replicas only: each rank trains its own copy (a data-parallel all-reduce of the six table gradients is not built)",
                    "reference_logged": "7.0 s/iter at batch 320 (models/sr_x2sdy/lutft.log), unspecified 2022 GPU"},
-        "roofline": {"bound": "lds_atomic", "kernel": "ft_stage_bwd4 (final-stage backward: table gradients summed in an LDS copy of the tube band, flushed once per workgroup and mode)",
+        "roofline": {"bound": "lds_rmw", "kernel": "ft_stage_bwd4 (final-stage backward: table gradients summed in per-group LDS caches of band rows, evicted into an LDS copy of the tube band, flushed once per workgroup and mode)",
                      "table_gradient_adds_per_step": adds,
                      "achieved": round(adds / (ms * 1e-3) / 1e9, 2), "unit": "G float adds/s (whole step time as the denominator)",
-                     "peak": round(256 * 32 * CLOCK_GHZ, 1), "peak_how": "256 CUs x 32 ds_add_f32 lanes per LDS cycle (a 4-byte LDS access serves 32 lanes per cycle: MI355X_MICROARCH.md, LDS) x 2.4 GHz",
-                     "frac": round(adds / (ms * 1e-3) / 1e9 / (256 * 32 * CLOCK_GHZ), 4),
+                     "peak": round(256 * 64 / 7.0 * CLOCK_GHZ, 1), "peak_how": "256 CUs x 64 lanes per 7.0 LDS cycles (read + add + write of private addresses, measured: profiles/r03_ubench_lds_atomic.txt) x 2.4 GHz; as ds_add_f32 (48 cycles per wave instruction) the peak would be 819",
+                     "frac": round(adds / (ms * 1e-3) / 1e9 / (256 * 64 / 7.0 * CLOCK_GHZ), 4),
                      "memory_side_float_atomics": {"peak": 1300.0, "unit": "GB/s of added bytes (MI355X_MICROARCH.md, Global float atomics)",
                                                    "if_every_add_went_to_memory": round(adds * 4 / (ms * 1e-3) / 1e9, 1)},
                      "counters": counters.get("kernels") if counters else None, "traffic": None},

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/mulut.h"
 #include "mulut_core.h"
@@ -168,6 +169,16 @@ __global__ void __launch_bounds__(256) ft_stage_fwd(FtArgs a) {
     });
 }
 
+// float add into LDS as ds_add_f32: an atomicAdd on a pointer the compiler cannot prove to be LDS (here: one of two targets chosen
+// at run time) becomes flat_atomic_add_f32, which reaches the LDS through the texture path
+__device__ __forceinline__ void lds_add_f32(float *p, float v) {
+    // (as an instruction of its own: written as an atomic on an address_space(3) pointer it is still merged with the global
+    // atomic of the other branch into one flat atomic on a selected pointer.)  The compiler does not count this LDS operation:
+    // LDS returns in order, so its own waits can only get stricter, and lds_adds_done() drains before a barrier publishes the sums.
+    asm volatile("ds_add_f32 %0, %1" : : "v"((uint32_t)(uintptr_t)p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_adds_done() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
+
 // Backward of one stage.  A workgroup owns 256 consecutive sites.  Per site (one thread): recompute the stage forward for
 // the clamp mask, g = dL/d pred; then per pass the five rows' dot products with g give the input gradient (one atomic
 // per rank into the source pixel: adjacent sites hit adjacent floats, i.e. well-shaped 256-byte atomic instructions).
@@ -238,7 +249,7 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
                     // one float per item: LDS tube band when the pass is inside the tube, else global memory
                     const float v = wq * g[0];
                     if (v != 0.0f) {
-                        if (p.in_tube) atomicAdd(&s_band[m * kTubeSlots + p.tslot[j]], v);
+                        if (p.in_tube) lds_add_f32(&s_band[m * kTubeSlots + p.tslot[j]], v);
                         else atomicAdd(&gtab[p.idx[j]], v);
                     }
                 } else {
@@ -268,6 +279,7 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
         }
     }
     if constexpr (U == 1) {
+        lds_adds_done();
         __syncthreads();
         // flush the workgroup's tube-band sums: contiguous floats, a wave adds 256 bytes at a time
         for (int m = 0; m < a.M; ++m) {
@@ -283,92 +295,184 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
     }
 }
 
-// Backward of a stage with 16-float rows (u == 4), 1024 sites per workgroup.  Photograph-like batches send thousands of
-// sites to the same few hundred table rows; memory-side float atomics serialise per address, so the table gradient of
-// the rows inside the tube (mulut_core.h: the rows smooth content uses) is first summed in an LDS copy of the tube band
-// (1041 x 16 floats, one mode at a time, ds_add_f32) and flushed once per workgroup and mode as contiguous atomics; only
-// passes outside the tube add to global memory directly (16 lanes per row: 64-byte segments).
-// LDS: [ band gradient 1041 x 16 f32 ][ g of the 1024 sites, 17 floats each ][ per-row items: table row, tube slot, weight / q ]
-constexpr int kFtB4Sites = 1024;
-constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Sites * 12;
+// Backward of a stage with 16-float rows (u == 4), kFtB4Sites sites per workgroup.  Photograph-like batches send thousands of
+// sites to the same few hundred table rows, and float adds are dear wherever they meet: memory-side atomics serialise per
+// address, and an LDS float add (ds_add_f32) occupies the CU's LDS pipeline for 48 cycles per wave instruction whatever its
+// addresses (tools/ubench/ubench_lds_atomic.hip; an integer add or a plain write takes 3.8, read + add + write of a private
+// address 7).  So the table gradient is summed on three levels:
+//   1. a 16-lane group (lane = row element) owns 16 consecutive sites and a PRIVATE 16-entry cache of band rows in LDS, direct
+//      mapped by slot mod 16 -- the 16 corners of one MSB cell have 16 different residues (the tube strides are 11, 2, 12, 8
+//      mod 16), so a group whose sites stay inside a cell never evicts.  A hit is read + add + write, no atomic;
+//   2. an evicted entry (the sites moved on to another cell) and, at the end of a mode, every entry goes into the workgroup's LDS
+//      copy of the tube band (1041 x 16 floats) with ds_add_f32;
+//   3. the band is flushed once per workgroup and mode as contiguous memory-side atomics.
+// Passes outside the tube add to global memory directly (16 lanes per row: 64-byte segments).
+// The sites of a group ARE its 16 lanes, so nothing crosses a wave: at the start of a pass a site lane publishes, for each of
+// the five path vertices, (table row | tube slot, weight / q) in its LDS items; the group walks its 16 sites vertex by vertex
+// (the rows themselves -- one coalesced 64-byte read per site -- are requested one vertex ahead), and the dot product g . row
+// -- the input gradient's ingredient -- comes back to the site's lane as a 16-lane DPP sum through the item.  The cache tags live
+// in registers (lane c of the group holds entry c's): a lookup is two compares and a ballot.  No barrier inside a mode.
+// LDS: [ band gradient 1041 x 16 f32 ][ g of the sites, 17 floats each ][ caches: 16 x 16 f32 per group ][ items: 5 per site ]
+#ifndef MULUT_FT_ABL
+#define MULUT_FT_ABL 0      // timing-only ablations (tools/ab_bench.py variants ftabl1..5): never in the product build
+#endif
+constexpr int kFtB4Sites = 512, kFtB4Groups = kFtB4Sites / 16;
+constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Groups * 16 * 16 * 4 + 5 * kFtB4Sites * 8;
+static_assert(kFtB4Lds <= 160 * 1024, "ft_stage_bwd4: LDS");
+
+__device__ __forceinline__ float ft_sum16(float v) {      // sum over the 16 lanes of a DPP row; every lane gets it
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));      // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));      // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, false));      // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false));      // row_ror:1
+    return v;
+}
+
+struct FtItem {
+    int key;        // table row | (tube slot + 1) << 17 (slot + 1 == 0: outside the tube); -1: no site
+    float wq;       // weight / q of the vertex; the group overwrites it with g . row for the site's lane
+};
+
 __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
-    constexpr int U = 4, EL = 16, NT = kFtB4Sites;
+    constexpr int U = 4, EL = 16, NT = kFtB4Sites, NG = kFtB4Groups;
     extern __shared__ __attribute__((aligned(16))) uint8_t ft_smem[];
     float *s_band = (float *)ft_smem;
     float (*s_g)[17] = (float (*)[17])(ft_smem + kTubeSlots * 16 * 4);
-    int *s_idx = (int *)(ft_smem + kTubeSlots * 16 * 4 + NT * 17 * 4);
-    int *s_slot = s_idx + NT;
-    float *s_wq = (float *)(s_slot + NT);
-    const long long nsite = (long long)a.B * a.C * a.H * a.W;
-    const long long s = (long long)blockIdx.x * NT + threadIdx.x;
-    const bool valid = s < nsite;
-    const long long sc = valid ? s : nsite - 1;
-    const int x = (int)(sc % a.W), y = (int)((sc / a.W) % a.H);
-    const long long bc = sc / ((long long)a.W * a.H);
+    float *s_cache = (float *)(ft_smem + kTubeSlots * 16 * 4 + NT * 17 * 4);
+    FtItem *s_item = (FtItem *)(s_cache + NG * 256);      // [5][NT]
+    // a group's 16 sites are a 4x4 block of one plane (lane = 4 * row + column): neighbours in both directions share MSB cells, so
+    // the group's cache sees fewer cell changes than with 16 sites along a row; lanes beyond the plane shadow its last site
+    const int e = (int)threadIdx.x & 15, grp = (int)threadIdx.x >> 4, first = grp * 16, gshift = (int)threadIdx.x & 48;
+    const int bw = (a.W + 3) / 4, bh = (a.H + 3) / 4;
+    const long long nblock = (long long)a.B * a.C * bh * bw, block = (long long)blockIdx.x * NG + grp;
+    const long long blk = block < nblock ? block : nblock - 1;
+    const long long bc = blk / ((long long)bh * bw);
+    const int brem = (int)(blk % ((long long)bh * bw));
+    const int y0 = (brem / bw) * 4 + (e >> 2), x0 = (brem % bw) * 4 + (e & 3);
+    const bool valid = block < nblock && y0 < a.H && x0 < a.W;
+    const int y = imin(y0, a.H - 1), x = imin(x0, a.W - 1);
     const float *plane = a.x + bc * a.H * a.W;
     float *gplane = a.gx + bc * a.H * a.W;
-    float g[EL];
     {
         float pred[EL];
+#if MULUT_FT_ABL == 2
+        for (int q = 0; q < EL; ++q) pred[q] = 100.0f;
+#else
         ft_site_forward<U>(a, plane, y, x, pred);
+#endif
         const float avg = a.is_last ? (float)a.M : (float)(4 * a.M), bias = a.is_last ? 0.0f : 127.0f;
         const float *pg = a.gout + bc * (long long)(a.H * U) * (a.W * U);
         static_for<0, EL>([&](auto E) {
             constexpr int eo = E;
             const float t = pred[eo] / avg + bias;
             const float go = pg[(long long)(y * U + eo / U) * (a.W * U) + (x * U + eo % U)];
-            g[eo] = (valid && t >= 0.0f && t <= 255.0f) ? go / avg : 0.0f;
-            s_g[threadIdx.x][eo] = g[eo];
+            s_g[threadIdx.x][eo] = (valid && t >= 0.0f && t <= 255.0f) ? go / avg : 0.0f;
         });
     }
-    const int e = (int)threadIdx.x & 15;
+    float *cache = s_cache + grp * 256;      // [16 entries][16 elements]
     for (int m = 0; m < a.M; ++m) {
         const float *tab = a.w[m];
         float *gtab = a.gw[m];
         const int di[3] = {a.di[m][0], a.di[m][1], a.di[m][2]}, dj[3] = {a.dj[m][0], a.dj[m][1], a.dj[m][2]};
         for (int i = threadIdx.x; i < kTubeSlots * 16; i += NT) s_band[i] = 0.0f;
+        int tagreg = -1;      // tag of cache entry e of this group
+        __syncthreads();      // band zeroed (and, first trip, s_g written) before any group adds into it
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
-            FtPass p;
-            ft_pass_setup(plane, a.H, a.W, y, x, r, di, dj, p);
-            const int eo = eo_of_elem<U>(r, e);
-            float dprev = 0.0f;
-#pragma unroll 1
-            for (int j = 0; j < 5; ++j) {
-                const int ij = j == 0 ? p.idx[0] : j == 1 ? p.idx[1] : j == 2 ? p.idx[2] : j == 3 ? p.idx[3] : p.idx[4];
-                const int tj = j == 0 ? p.tslot[0] : j == 1 ? p.tslot[1] : j == 2 ? p.tslot[2] : j == 3 ? p.tslot[3] : p.tslot[4];
-                const float wj = j == 0 ? p.wt[0] : j == 1 ? p.wt[1] : j == 2 ? p.wt[2] : j == 3 ? p.wt[3] : p.wt[4];
-                const float *row = tab + (long long)ij * EL;
-                float acc = 0.0f;
+            int src[4];
+            {
+                FtPass p;
+                ft_pass_setup(plane, a.H, a.W, y, x, r, di, dj, p);
 #pragma unroll
-                for (int q = 0; q < EL; ++q) {
-                    const int el = r == 0 ? q : r == 1 ? (U - 1 - q % U) * U + q / U : r == 2 ? EL - 1 - q : (q % U) * U + (U - 1 - q / U);   // row_elem
-                    acc += g[q] * row[el];
+                for (int j = 0; j < 5; ++j) {
+                    FtItem it;
+                    it.key = valid ? (p.idx[j] | ((p.in_tube ? p.tslot[j] + 1 : 0) << 17)) : -1;
+                    it.wq = p.wt[j] / (float)kQ;
+                    s_item[j * NT + threadIdx.x] = it;
                 }
-                if (j > 0) {     // d/d f of rank j = (p_j - p_{j-1}) . g / q
-                    const int sj = j == 1 ? p.src[0] : j == 2 ? p.src[1] : j == 3 ? p.src[2] : p.src[3];
-                    const float df = (acc - dprev) / (float)kQ;
-                    if (df != 0.0f) atomicAdd(&gplane[sj], df);
-                }
-                dprev = acc;
-                __syncthreads();      // the previous row's items have been consumed (first trip: band zeroed, s_g written)
-                s_idx[threadIdx.x] = valid ? ij : -1;
-                s_slot[threadIdx.x] = p.in_tube ? tj : -1;
-                s_wq[threadIdx.x] = wj / (float)kQ;
-                __syncthreads();
-                for (int it = (int)threadIdx.x >> 4; it < NT; it += NT / 16) {
-                    const int idx = s_idx[it];
-                    if (idx < 0) continue;
-                    const float v = s_wq[it] * s_g[it][eo];
-                    if (v == 0.0f) continue;
-                    const int slot = s_slot[it];
-                    if (slot >= 0) atomicAdd(&s_band[slot * 16 + e], v);
-                    else atomicAdd(&gtab[(long long)idx * EL + e], v);
-                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) src[j] = p.src[j];
             }
+            // (the 16 sites are this group's own lanes: LDS serves a wave's operations in order, the fences only keep the compiler
+            // from moving the accesses across each other)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int eo = eo_of_elem<U>(r, e);
+#if MULUT_FT_ABL != 1
+            int key[2][16];
+            float wq[2][16], rowv[2][16];
+            auto request = [&](auto J) {      // items of vertex J and their table rows
+                constexpr int jj = J, b = jj & 1;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const FtItem it = s_item[jj * NT + first + k];
+                    key[b][k] = it.key; wq[b][k] = it.wq;
+#if MULUT_FT_ABL == 5
+                    rowv[b][k] = 1.0f;
+#else
+                    rowv[b][k] = it.key >= 0 ? tab[(long long)(it.key & 0x1FFFF) * EL + e] : 0.0f;
+#endif
+                }
+            };
+            request(std::integral_constant<int, 0>{});
+            static_for<0, 5>([&](auto J) {
+                constexpr int j = J, b = j & 1;
+                if constexpr (j < 4) request(std::integral_constant<int, j + 1>{});
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (key[b][k] < 0) continue;      // (uniform in the group)
+                    const float gv = s_g[first + k][eo], v = wq[b][k] * gv;
+                    const float d = ft_sum16(gv * rowv[b][k]);
+                    if (e == 0) s_item[j * NT + first + k].wq = d;
+#if MULUT_FT_ABL != 4
+                    const int slot = (key[b][k] >> 17) - 1;
+                    if (slot >= 0) {
+                        const int c = slot & 15;
+                        const bool mine = e == c;
+                        const unsigned long long hits = __ballot(mine && tagreg == slot);
+#if MULUT_FT_ABL == 7
+                        const bool hit = hits != 12345ull;
+#else
+                        const bool hit = ((hits >> gshift) & 0xFFFFull) != 0ull;
+#endif
+                        float *cp = cache + c * 16 + e;
+                        const float old = *cp;
+                        *cp = hit ? old + v : v;
+                        if (!hit) {      // the sites moved on to another cell: the entry's sum goes into the band
+                            const int t = __shfl(tagreg, c, 16);
+#if MULUT_FT_ABL != 6
+                            if (t >= 0) lds_add_f32(&s_band[t * 16 + e], old);
+#endif
+                            if (mine) tagreg = slot;
+                        }
+                    } else if (v != 0.0f) atomicAdd(&gtab[(long long)(key[b][k] & 0x1FFFF) * EL + e], v);
+#endif
+                }
+            });
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // d/d f of rank j = (g . p_j - g . p_{j-1}) / q, to the source pixel of that rank
+            float dprev = s_item[threadIdx.x].wq;
+#pragma unroll
+            for (int j = 1; j < 5; ++j) {
+                const float cur = s_item[j * NT + threadIdx.x].wq;
+                const float df = (cur - dprev) / (float)kQ;
+#if MULUT_FT_ABL != 3
+                if (valid && df != 0.0f) atomicAdd(&gplane[src[j - 1]], df);
+#else
+                if (valid && df == 123.456f) atomicAdd(&gplane[src[j - 1]], df);
+#endif
+                dprev = cur;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+        // the group's cache into the band, then the band's rows (tube rows of anchor MSB A, 16 lanes per row) into the table gradient
+#pragma unroll 1
+        for (int c = 0; c < 16; ++c) {
+            const int t = __shfl(tagreg, c, 16);
+            if (t >= 0) lds_add_f32(&s_band[t * 16 + e], cache[c * 16 + e]);
+        }
+        lds_adds_done();
         __syncthreads();
-        // flush this mode's band sums: tube rows of anchor MSB A, 16 lanes per row
         for (int A = 0; A < kL; ++A)
             for (int i = (int)threadIdx.x >> 4; i < 125; i += NT / 16) {
                 const int B = A - 2 + i / 25, C = A - 2 + (i / 5) % 5, D = A - 2 + i % 5;
@@ -390,7 +494,8 @@ static hipError_t launch_ft(const FtArgs &a, bool backward, hipStream_t st) {
             const hipError_t e = mulut::raise_lds_limit((const void *)ft_stage_bwd4, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        const long long nb4 = (nsite + kFtB4Sites - 1) / kFtB4Sites;
+        const long long nblock4 = (long long)a.B * a.C * ((a.H + 3) / 4) * ((a.W + 3) / 4);      // 4x4 site blocks, one per 16-lane group
+        const long long nb4 = (nblock4 + kFtB4Groups - 1) / kFtB4Groups;
         hipLaunchKernelGGL(ft_stage_bwd4, dim3((unsigned)nb4), dim3(kFtB4Sites), (size_t)kFtB4Lds, st, a);
     } else if (backward) hipLaunchKernelGGL(ft_stage_bwd<U>, dim3((unsigned)nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(ft_stage_fwd<U>, dim3((unsigned)nb), dim3(256), 0, st, a);

@@ -29,6 +29,8 @@ COMPILER_VARIANTS = {
     "itminreg": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
     "nosched": ["-mllvm", "-enable-misched=0"],
     "o2": ["-O2"],
+    "ftabl1": ["-DMULUT_FT_ABL=1"], "ftabl2": ["-DMULUT_FT_ABL=2"], "ftabl3": ["-DMULUT_FT_ABL=3"], "ftabl4": ["-DMULUT_FT_ABL=4"], "ftabl5": ["-DMULUT_FT_ABL=5"], "ftabl6": ["-DMULUT_FT_ABL=6"], "ftabl7": ["-DMULUT_FT_ABL=7"],      # ft_stage_bwd4 timing ablations
+    "ftnt512": ["-DMULUT_FT_B4_SITES=512"], "ftnt768": ["-DMULUT_FT_B4_SITES=768"],
 }
 
 
