@@ -85,7 +85,9 @@ int mulut_pass(mulut_ctx *ctx, int stage, char mode, int r, const uint8_t *in_ch
                int32_t *out_q, void *stream);
 
 /* One whole stage (all modes x 4 rotations, average, +bias, round-half-even, clip): replaces one
- * iteration of the `for s in range(stages)` body (sr/4_test_lut.py:280-306).  N images. */
+ * iteration of the `for s in range(stages)` body (sr/4_test_lut.py:280-306).  N images.
+ * Any C >= 1 (here and in mulut_pipeline / mulut_pipeline_rows): the kernels take up to three channels per
+ * launch, images with more are run as groups of three (channels are independent in the reference too). */
 int mulut_stage(mulut_ctx *ctx, int stage, const uint8_t *in, int in_layout, uint8_t *out, int out_layout, int N,
                 int H, int W, int C, void *stream);
 

@@ -105,3 +105,45 @@ def test_lut_inspector():
     by = {(r["stage"], r["mode"]): r for r in recs}
     assert by[(2, "d")]["v_num"] == 16 and by[(2, "d")]["upscale"] == 4 and by[(2, "d")]["min"] == -120
     assert by[(1, "s")]["v_num"] == 1 and by[(1, "s")]["lut_name"] == "LUT_ft" and by[(1, "s")]["bits"] == 4
+
+
+def test_tube2_private_registers_stay_private(tmp_path):
+    """stage_tube2_kernel keeps the rows of the pass in flight in v88..v127 across asm statements (tools/gen_tube2_asm.py): the
+    compiler must never allocate them.  Audit of the gfx950 ISA: inside the kernel, outside the inline-asm blocks, no
+    instruction names v88 or above."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "mulut_amd", "csrc", "mulut_kernels.hip")
+    out = str(tmp_path / "k.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-inline-asm", "-Wno-pass-failed",
+                           "--cuda-device-only", "-S", "-o", out, src], stderr=subprocess.DEVNULL)
+    inc = open(os.path.join(ROOT, "mulut_amd", "csrc", "mulut_tube2_asm.inc")).read()
+    row0 = int(re.search(r"#define TUBE2_ROW0 (\d+)", inc).group(1))
+    reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+    kernels, name, in_asm, bad = 0, None, False, []
+    for line in open(out):
+        m = re.match(r"^(_ZN5mulut18stage_tube2_kernel\w+):", line)
+        if m:
+            name, in_asm = m.group(1), False
+            kernels += 1
+            continue
+        if name is None:
+            continue
+        if "s_endpgm" in line:
+            name = None
+            continue
+        if "#ASMSTART" in line:
+            in_asm = True
+        elif "#ASMEND" in line:
+            in_asm = False
+        elif not in_asm and not line.lstrip().startswith((";", ".")):
+            for a, lo, hi in reg.findall(line.split(";")[0]):
+                top = int(a) if a else int(hi)
+                if top >= row0:
+                    bad.append((name, line.strip()))
+    assert kernels == 3, kernels          # generic, planar, rgb
+    assert not bad, bad[:5]
