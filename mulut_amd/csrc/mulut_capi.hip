@@ -414,8 +414,9 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.use_f32 = ctx->f32_ok[last ? 1 : 0];
     a.epi_c = last ? ctx->epi_c : 127.0f;
     a.use_fma = last ? ctx->fma_ok : ctx->fma1_ok;
-    // u == 4, <= 3 modes: the LDS kernels (tube bands resident); final_kernel 5 = on every tile, 0 / 6 = hybrid with the per-tile statistic
-    const bool tube = u == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1;
+    // u == 4: the LDS kernels (tube bands resident) for up to 3 modes, and for longer lists that stage_tube2_kernel takes as a multiset of
+    // its three patterns; final_kernel 5 = on every tile, 0 / 6 = hybrid with the per-tile statistic
+    const bool tube = u == 4 && ctx->final_kernel != 1 && (ctx->n_modes <= 3 || (ctx->tube2 && C <= 3 && stage_tube2_supported(a)));
     const bool hybrid = tube && ctx->final_kernel != 5;
     a.verdict = nullptr;
     a.verdict_take = -1;
@@ -857,8 +858,11 @@ const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (!ctx || !ctx->configured) return "";
     if (!is_final || ctx->scale == 1) return stage_u1_name(ctx->first_kernel);
     if (ctx->scale == 2 && ctx->n_modes <= 3 && ctx->final_kernel != 1) return "stage_u1t_kernel<2> + stage_up_fix_site_kernel<2>";
-    if (ctx->scale == 4 && ctx->n_modes <= 3 && ctx->final_kernel != 1) {
-        const bool t2 = ctx->tube2 && !strcmp(ctx->modes, "sdy");
+    // (as run_stage decides: the pipelined kernel takes every list that uses all of s, d, y, up to kMaxTube2Modes modes, when the float
+    // epilogue is exact for the divisor)
+    const bool all3 = strchr(ctx->modes, 's') && strchr(ctx->modes, 'd') && strchr(ctx->modes, 'y');
+    const bool t2 = ctx->tube2 && all3 && ctx->n_modes <= kMaxTube2Modes && ctx->f32_ok[1];
+    if (ctx->scale == 4 && (ctx->n_modes <= 3 || t2) && ctx->final_kernel != 1) {
         if (ctx->final_kernel == 5) return t2 ? "stage_tube2_kernel<rgb> + stage_up_fix2_kernel" : "stage_tube_kernel<rgb> + stage_up_fix2_kernel";
         if (ctx->detail_kernel == 0)
             return t2 ? "hybrid: tile_stat_kernel + stage_tube2_kernel<rgb> (smooth tiles; hand-scheduled LDS pipeline, one 16x4 tile per wave) + stage_slab_kernel (detailed tiles, anchor slabs in LDS)"

@@ -74,7 +74,9 @@ struct PassArgs {
 };
 
 struct BandArgs {
-    const void *band[3];   // device images of the tube band of each mode's table (mulut_core.h: kTubeBandBytes / kTube2BandBytes / kTube1BandBytes)
+    const void *band[kMaxModes];   // device images of the tube band of each mode's table (mulut_core.h: kTubeBandBytes / kTube2BandBytes / kTube1BandBytes)
+    uint32_t scale[3];     // stage_tube2_kernel only (its launcher fills it): band[p] is PATTERN p's band (s, d, y) and scale[p] how many
+                           // modes of the list have that pattern, in both 16-bit halves: the band is multiplied by it while it is staged
 };
 
 enum K2Out { kOutGeneric = 0, kOutPlanarU4 = 1, kOutPackedRGBU4 = 2 };
@@ -130,6 +132,7 @@ hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode
 const char *stage_tube_name(int out_mode);
 // the same kernel with every LDS read hand-scheduled (rows of the next pass in flight under the current pass's MACs); built for
 // the mode lists stage_tube2_supported() accepts
+constexpr int kMaxTube2Modes = 4;
 bool stage_tube2_supported(const StageArgs &a);
 hipError_t launch_stage_tube2(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 // recompute the pixels listed in a.fix_list[0 .. *a.fix_count) from the full tables (u == 4)

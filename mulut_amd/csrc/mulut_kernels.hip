@@ -11,6 +11,7 @@
 //
 // No MFMA: this is gather + lerp, bounded by LDS/L1 gather rate and VALU, not by a contraction.
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #include <mutex>
 #include <set>
@@ -964,12 +965,21 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
 #else
 #define T2_STAMP(PH) do { } while (0)
 #endif
-    // bands: slot = pattern id of the mode; patterns the mode list lacks are never read
+    // bands: slot = pattern id.  A mode list is a multiset of patterns and the numerator a plain sum over its modes, so a pattern that
+    // occurs k times is computed once on a band of k-fold values (fields <= 255 k; a merged rotation pair sums to <= 8160 x modes)
     static_for<0, M>([&](auto MI) {
         constexpr int pat = t2_pat(PATS, MI);
         const uint4 *src = (const uint4 *)b.band[MI];
         uint4 *dst = (uint4 *)(smem + pat * kTubeBandBytes);
-        for (int i = threadIdx.x; i < kTubeBandBytes / 16; i += NT) dst[i] = src[i];
+        const uint32_t k = b.scale[MI];
+        if (k == 0x00010001u) {
+            for (int i = threadIdx.x; i < kTubeBandBytes / 16; i += NT) dst[i] = src[i];
+        } else {
+            for (int i = threadIdx.x; i < kTubeBandBytes / 16; i += NT) {
+                const uint4 v = src[i];
+                dst[i] = make_uint4(pk_mad(v.x, k, 0u), pk_mad(v.y, k, 0u), pk_mad(v.z, k, 0u), pk_mad(v.w, k, 0u));
+            }
+        }
     });
     if (threadIdx.x == 0) *s_next = 0u;
     __syncthreads();          // the only barrier of the kernel
@@ -1031,7 +1041,7 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
             auto acc_start = [&]() {
                 acc.clear();
                 if constexpr (OUT != kOutGeneric) {
-                    const uint32_t nb = pk_dup((uint32_t)(65536 - 128 * kQ * 4 * M));
+                    const uint32_t nb = pk_dup((uint32_t)(65536 - 128 * kQ * 4 * a.M));      // (a.M: the modes of the list, not the patterns)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) acc.lo02[k] = acc.hi02[k] = nb;
                 }
@@ -1144,15 +1154,28 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
 
 constexpr int kT2PatsSDY = 3 | (0 << 2) | (1 << 4) | (2 << 6);
 
-// pattern list of the launch as PATS (0 if the list is not one stage_tube2_kernel is built for)
-static int tube2_pats(const StageArgs &a) {
-    int pats = a.M;
-    for (int m = 0; m < a.M; ++m) pats |= (a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0) << (2 + 2 * m);
-    return pats == kT2PatsSDY ? pats : 0;
+// how many modes of the launch have pattern s, d, y; false if a mode has none of them
+static bool tube2_counts(const StageArgs &a, int (&cnt)[3]) {
+    cnt[0] = cnt[1] = cnt[2] = 0;
+    for (int m = 0; m < a.M; ++m) {
+        int di[3], dj[3], p = -1;
+        for (int q = 0; q < 3 && p < 0; ++q) {
+            pattern_offsets("sdy"[q], di, dj);
+            if (memcmp(di, a.di[m], sizeof(di)) == 0 && memcmp(dj, a.dj[m], sizeof(dj)) == 0) p = q;
+        }
+        if (p < 0) return false;
+        ++cnt[p];
+    }
+    return true;
 }
+// The kernel is built for the pattern set {s, d, y}; any mode list that uses all three runs on it, in any order and with repeats
+// (kMaxTube2Modes in all: the sign-extending epilogue needs |K| <= 8192 x modes to fit 16 bits).  Lists that lack a pattern would
+// pay for its passes: they stay with stage_tube_kernel.
 bool stage_tube2_supported(const StageArgs &a) {
+    int cnt[3];
     // the float epilogue must be exact for the divisor (StageArgs::use_f32, proven at configure time), the bias the numerator bias of a final stage
-    return a.C <= 3 && a.M <= 3 && a.site_flags == nullptr && tube2_pats(a) != 0 && a.use_f32 && a.bias_num == 0;
+    return a.C <= 3 && a.M <= kMaxTube2Modes && a.site_flags == nullptr && tube2_counts(a, cnt) && cnt[0] && cnt[1] && cnt[2] && a.use_f32 &&
+           a.bias_num == 0;
 }
 
 template <int OUT>
@@ -1169,8 +1192,17 @@ static hipError_t launch_tube2_t(const StageArgs &a, const BandArgs &b, int num_
     return hipGetLastError();
 }
 
-hipError_t launch_stage_tube2(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st) {
-    if (!stage_tube2_supported(a)) return hipErrorInvalidValue;
+// bm.band[m] = band of MODE m of the list (as for launch_stage_tube); handed to the kernel per pattern with its multiplicity
+hipError_t launch_stage_tube2(const StageArgs &a, const BandArgs &bm, int out_mode, int num_cus, hipStream_t st) {
+    int cnt[3];
+    if (!stage_tube2_supported(a) || !tube2_counts(a, cnt)) return hipErrorInvalidValue;
+    BandArgs b;
+    memset(&b, 0, sizeof(b));
+    for (int m = 0; m < a.M; ++m) {
+        const int p = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
+        b.band[p] = bm.band[m];
+        b.scale[p] = (uint32_t)cnt[p] * 0x00010001u;
+    }
     if (out_mode == kOutPlanarU4) return launch_tube2_t<kOutPlanarU4>(a, b, num_cus, st);
     if (out_mode == kOutPackedRGBU4 && a.C == 3) return launch_tube2_t<kOutPackedRGBU4>(a, b, num_cus, st);
     return launch_tube2_t<kOutGeneric>(a, b, num_cus, st);

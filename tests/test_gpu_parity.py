@@ -447,6 +447,28 @@ def test_more_than_four_modes_at_scale_4(modes):
         e.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("modes", ["dys", "sdys", "yssd", "ddys", "sdyy"])
+def test_mode_lists_as_pattern_multisets(modes):
+    """A mode list is a multiset of patterns: stage_tube2_kernel (built for s, d, y) takes any list that uses all three, in any
+    order and with repeats up to four modes, by staging k-fold bands.  Smooth content (so that the tube kernel does the work),
+    extreme tables (field capacity with a doubled pattern) and random ones, every tile on the tube kernel and the hybrid."""
+    from mulut_amd import MuLUTEngine
+    rng = np.random.default_rng(len(modes) + ord(modes[0]))
+    img = np.stack([natural_image(40, 72, 3, seed=s) for s in (1, 2)])
+    for val in (127, -128, None):
+        luts = {"s1_%s" % m: (np.full((17 ** 4, 16), val, np.int8) if val is not None else rng.integers(-128, 128, (17 ** 4, 16), dtype=np.int8))
+                for m in set(modes)}
+        e = MuLUTEngine(0).configure(1, modes, 4, 4).set_lut_dict(luts)
+        want = np.stack([c_oracle.pipeline(luts, 1, modes, 4, im) for im in img])
+        for sel in (5, 0, 1):
+            e.set_tuning("final_stage_kernel", sel)
+            assert np.array_equal(e.pipeline(dev(img)).cpu().numpy(), want), (modes, val, sel)
+            if sel == 5:
+                assert "tube2" in e.kernel_name(1), e.kernel_name(1)
+        e.close()
+
+
 def _strip_rank(rank, world, port, q):
     """one rank of the config-3 rehearsal: real engine, strips + halo, gather on rank 0 (gloo moves host memory)"""
     import torch.distributed as dist
