@@ -430,7 +430,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
                           oy1 <= ctx->k1_oy1;      // the marks cover exactly the rows that launch wrote: never index past its tile grid
     ctx->k1_valid = false;
     if (u == 1) {
-        const bool tube1 = (ctx->first_kernel == 0 || ctx->first_kernel == 3) && ctx->n_modes <= 3 &&
+        // (any mode list: the bands live in LDS per PATTERN, a repeated pattern is simply computed again into the int32 sum)
+        const bool tube1 = (ctx->first_kernel == 0 || ctx->first_kernel == 3) &&
                            (unsigned long long)N * C * H * W < (1ull << 32);
         if (!tube1) {
             MAIN_KERNEL(ctx, stage, st, launch_stage_u1(a, st, 0));
@@ -463,7 +464,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     int mode = kOutGeneric;
     if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || (C == 1 && packed_ok))) mode = kOutPlanarU4;
     else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3 && packed_ok) mode = kOutPackedRGBU4;
-    if (u == 2 && ctx->n_modes <= 3 && ctx->final_kernel != 1 && (unsigned long long)N * C * H * W < (1ull << 32)) {
+    // (merged 16-bit fields hold 4 modes)
+    if (u == 2 && ctx->n_modes <= 4 && ctx->final_kernel != 1 && (unsigned long long)N * C * H * W < (1ull << 32)) {
         // u == 2 final stage on the tube band (the 1-byte-row kernel family with 4-value rows); flagged sites recomputed from the full table
         rc = ensure_fix(ctx, (size_t)N * C * (oy1 - oy0) * W);
         if (rc) return rc;
@@ -634,7 +636,7 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
         stage_band_tile(tw, th);
         int rc = ensure_verdict(ctx, (size_t)N * ((W + tw - 1) / tw) * ((H + th - 1) / th));
         if (rc) return rc;
-        if (ctx->n_modes <= 3) {
+        {
             const bool u1 = ctx->stages > 1 || ctx->scale == 1;
             rc = ensure_fix(ctx, (size_t)N * H * W * ((u1 || ctx->scale == 2 || ctx->scale == 4) ? (size_t)(C > 3 ? C : 3) : 1));
             if (rc) return rc;
@@ -857,7 +859,7 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
 const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (!ctx || !ctx->configured) return "";
     if (!is_final || ctx->scale == 1) return stage_u1_name(ctx->first_kernel);
-    if (ctx->scale == 2 && ctx->n_modes <= 3 && ctx->final_kernel != 1) return "stage_u1t_kernel<2> + stage_up_fix_site_kernel<2>";
+    if (ctx->scale == 2 && ctx->n_modes <= 4 && ctx->final_kernel != 1) return "stage_u1t_kernel<2> + stage_up_fix_site_kernel<2>";
     // (as run_stage decides: the pipelined kernel takes every list that uses all of s, d, y, up to kMaxTube2Modes modes, when the float
     // epilogue is exact for the divisor)
     const bool all3 = strchr(ctx->modes, 's') && strchr(ctx->modes, 'd') && strchr(ctx->modes, 'y');

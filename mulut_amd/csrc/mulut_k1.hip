@@ -690,7 +690,7 @@ static hipError_t launch_u1t_t(const StageArgs &a, const BandArgs &b, unsigned d
 }
 
 hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st) {
-    if (a.C > 3 || a.M > 3 || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
+    if (a.C > 3 || a.M > kMaxModes || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
     return launch_u1t_t<1>(a, b, detail_per_1024, num_cus, st);
 }
 
@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(256) stage_up_fix_site_kernel(StageArgs a) {
 // the same kernel family on a FINAL stage with u == 2 (4-value rows, 2 x 2 output blocks): b.band[m] = 8-byte-per-slot
 // tube band; no tile routing; flagged sites go to stage_up_fix_site_kernel through a.fix_list
 hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
-    if (a.C > 3 || a.M > 3 || !a.fix_list || !a.fix_count || a.verdict_take >= 0) return hipErrorInvalidValue;
+    if (a.C > 3 || a.M > 4 || !a.fix_list || !a.fix_count || a.verdict_take >= 0) return hipErrorInvalidValue;
     hipError_t e = launch_u1t_t<2>(a, b, 0u, num_cus, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(stage_up_fix_site_kernel<2>, dim3((unsigned)(4 * num_cus)), dim3(256), 0, st, a);

@@ -469,6 +469,25 @@ def test_mode_lists_as_pattern_multisets(modes):
         e.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("stages,scale,modes", [(2, 4, "sdys"), (2, 2, "ydsd"), (3, 1, "sdysdysd"), (2, 4, "sdysd"), (2, 2, "ssdyy")])
+def test_long_mode_lists_in_cascades(stages, scale, modes):
+    """More than three modes through the LDS kernels of the non-final stages (bands per pattern; any list), the x2 final stage
+    (up to four modes) and the x4 final stage (multisets up to four modes, per-rotation accumulators beyond), on smooth content."""
+    from mulut_amd import MuLUTEngine
+    img = np.stack([natural_image(52, 80, 3, seed=s) for s in (3, 4)])
+    luts = {}
+    for s in range(stages):
+        for m in set(modes):
+            luts["s%d_%s" % (s + 1, m)] = synthetic_lut(11 * s + ord(m), scale * scale if s + 1 == stages else 1)
+    e = MuLUTEngine(0).configure(stages, modes, scale, 4).set_lut_dict(luts)
+    want = np.stack([c_oracle.pipeline(luts, stages, modes, scale, im) for im in img])
+    for first in (0, 3, 2):
+        e.set_tuning("first_stage_kernel", first)
+        assert np.array_equal(e.pipeline(dev(img)).cpu().numpy(), want), (stages, scale, modes, first)
+    e.close()
+
+
 def _strip_rank(rank, world, port, q):
     """one rank of the config-3 rehearsal: real engine, strips + halo, gather on rank 0 (gloo moves host memory)"""
     import torch.distributed as dist
