@@ -140,11 +140,20 @@ def load_profile_json(name, workload=None):
     return rec
 
 
+ROLLED_BATCH = False      # --batch rolled: rounds 1-2's batch (two draws, the other frames rolled copies of them)
+
+
 def make_batch(dist, frames, h, w, seed):
+    """`frames` frames of the distribution.  D-natural / D-noise: every frame its own draw (SURVEY section 8d defines a frame as one
+    draw of the field).  Rounds 1 and 2 drew two frames and rolled them by (37 k, 91 k) pixels for the rest: the wrap-around
+    seams of a rolled smooth field are edges the field does not have (they cost the routed kernels ~7 % on D-natural);
+    `--batch rolled` still makes that batch."""
     from mulut_amd.synth import natural_frames, noise_frames, real_frames
     if dist == "real":
         return np.ascontiguousarray(real_frames(frames, h, w, REAL_PNG, seed))
     gen = natural_frames if dist == "natural" else noise_frames
+    if not ROLLED_BATCH:
+        return np.ascontiguousarray(gen(frames, h, w, 3, seed))
     base = gen(min(frames, 2), h, w, 3, seed)
     out = [np.roll(base[i % len(base)], (37 * (i // len(base)), 91 * (i // len(base))), axis=(0, 1))
            for i in range(frames)]
@@ -157,6 +166,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=32, help="LR frames per GPU per step (32: a 20-step timed region lasts ~0.17 s)")
+    ap.add_argument("--batch", choices=("draws", "rolled"), default="draws", help="draws: every frame its own draw of the distribution; rolled: rounds 1-2's batch")
     ap.add_argument("--lr-h", type=int, default=1080)
     ap.add_argument("--lr-w", type=int, default=1920)
     ap.add_argument("--dist", choices=["natural", "noise", "real"], default="natural",
@@ -171,6 +181,8 @@ def main():
                     help="2: headline (2-stage sdy x4); 4: LUT fine-tune step (fwd + bwd + Adam, bs 256 x 1x48x48); "
                          "5: deep cascade (4-stage sdy x2, seeded synthetic tables), eager vs hipGraph")
     args = ap.parse_args()
+    global ROLLED_BATCH
+    ROLLED_BATCH = args.batch == "rolled"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
 
@@ -306,7 +318,7 @@ def main():
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload, "frames_per_gpu": F, "lr": [H, W, 3], "stages": STAGES, "modes": MODES,
+            "config": {"workload": workload, "batch": "rolled copies of two draws (rounds 1-2)" if ROLLED_BATCH else "every frame its own draw", "frames_per_gpu": F, "lr": [H, W, 3], "stages": STAGES, "modes": MODES,
                        "scale": SCALE, "luts": "shipped sr_x2sdy fine-tuned int8 tables",
                        "parallelism": "frames sharded over %d GPU(s), no collective" % world,
                        **{"value_D-%s" % k: round(v, 2) for k, v in others.items()}},
