@@ -57,7 +57,6 @@ struct StageArgs {
     // stage_up_fix_kernel; *fix_count is zeroed by the host side before the stage
     uint32_t *fix_list;
     uint32_t *fix_count;
-    const uint8_t *site_flags;     // (always null: the per-pixel flag pass was retired in round 3; the tube kernels test every pass themselves)
     // 1-byte-row tube kernel: tile_list[tile] = 1 for the tiles it leaves to the full-table kernel (stage_u1w_kernel in
     // list mode); zeroed by the host side before the stage
     uint32_t *tile_list;

@@ -403,7 +403,7 @@ __device__ __forceinline__ void tube_rows(const uint8_t *smem, const TubePair &b
 
 // rotations R and R + 2 of one site and mode.  win = LDS byte address of the site's 5x5 window corner; k0 / ha16 / base_a:
 // the anchor's key, MSB term and slot term (+ this pattern's bias), hoisted by the caller.
-template <int PAT, int R, int PW, bool FLAGGED>
+template <int PAT, int R, int PW>
 __device__ __forceinline__ void tube_pair(const uint8_t *smem, uint32_t win, uint32_t k0, uint32_t ha16, uint32_t base_a, RotAcc<4> &acc, uint32_t &dirty) {
     constexpr int IMM = PAT * kTubeBandBytes - tube_bias(PAT);
     static_assert(IMM >= 0 && IMM + kTubeAll * 16 + kTubePlaneBytes <= 65535 && tube_bias(PAT) + kTubePlaneBytes <= 65536 && tube_bias(PAT) % 16 == 0,
@@ -417,23 +417,22 @@ __device__ __forceinline__ void tube_pair(const uint8_t *smem, uint32_t win, uin
     const uint32_t pc = w[(2 + yc) * PW + 2 + xc] | ((uint32_t)w[(2 - yc) * PW + 2 - xc] << 16);
     const uint32_t pd = w[(2 + yd) * PW + 2 + xd] | ((uint32_t)w[(2 - yd) * PW + 2 - xd] << 16);
     TubePair bp;
-    simplex4_tube_pair<FLAGGED>(k0, ha16, base_a, pb, pc, pd, bp);
+    simplex4_tube_pair<false>(k0, ha16, base_a, pb, pc, pd, bp);
     // A pass outside the tube still walks the band (any key combination maps to a slot inside it, so the reads stay
-    // in range) and adds garbage; the site is marked -- by site_flag_kernel ahead of this launch (FLAGGED), else by the
-    // per-pass test here -- and recomputed from the full table by stage_up_fix_kernel.
-    if constexpr (!FLAGGED) dirty |= bp.t_oob;
+    // in range) and adds garbage; the site is marked by the per-pass test here and recomputed from the full table by the fix-up kernel.
+    dirty |= bp.t_oob;
     tube_rows<R, 0, IMM>(smem, bp, acc);
     tube_rows<R + 2, 1, IMM>(smem, bp, acc);
 }
 
-template <int PAT, int PW, bool FLAGGED>
+template <int PAT, int PW>
 __device__ __forceinline__ void tube_mode(const uint8_t *smem, uint32_t win, uint32_t k0, uint32_t ha16, uint32_t ha27, RotAcc<4> &acc, uint32_t &dirty) {
     const uint32_t base_a = ha27 + pk_dup((uint32_t)tube_bias(PAT));
-    tube_pair<PAT, 0, PW, FLAGGED>(smem, win, k0, ha16, base_a, acc, dirty);
-    tube_pair<PAT, 1, PW, FLAGGED>(smem, win, k0, ha16, base_a, acc, dirty);
+    tube_pair<PAT, 0, PW>(smem, win, k0, ha16, base_a, acc, dirty);
+    tube_pair<PAT, 1, PW>(smem, win, k0, ha16, base_a, acc, dirty);
 }
 
-template <int OUT, int TW, int TH, bool FLAGGED>
+template <int OUT, int TW, int TH>
 __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArgs b) {
     constexpr int PW = TW + 2 * kTubeHaloX, PH = TH + 2 * kHalo;     // tile image: columns x0-4 .. x0+TW+3, rows y0-2 .. y0+TH+1
     constexpr int NT = TW * TH;
@@ -535,9 +534,7 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
             uint32_t o0[4], o1[4], o2[4];     // packed output rows of the finished channels (RGB path)
 #pragma unroll
             for (int k = 0; k < 4; ++k) o0[k] = o1[k] = o2[k] = 0;
-            // per channel: != 0 when some pass of the sample may have left the tube (FLAGGED: bit c of site_flag_kernel's byte)
-            const uint32_t sflags = FLAGGED ? (uint32_t)a.site_flags[((size_t)n * a.H + y) * a.W + x] : 0u;
-            uint32_t dmask = FLAGGED ? sflags & 7u : 0u;      // bit c: channel c is dirty
+            uint32_t dmask = 0u;      // bit c: channel c is dirty
 #pragma clang loop unroll(disable)
             for (int c = 0; c < a.C; ++c, win += 2 * PH * PW) {
                 uint32_t dirty = 0u;
@@ -548,9 +545,9 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
                 for (int mv = 0; mv < a.M; ++mv) {
                     const int m = __builtin_amdgcn_readfirstlane(mv);
                     const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;     // scalar
-                    if (pat == 0) tube_mode<0, PW, FLAGGED>(smem, win, k0, ha16, ha27, acc, dirty);
-                    else if (pat == 1) tube_mode<1, PW, FLAGGED>(smem, win, k0, ha16, ha27, acc, dirty);
-                    else tube_mode<2, PW, FLAGGED>(smem, win, k0, ha16, ha27, acc, dirty);
+                    if (pat == 0) tube_mode<0, PW>(smem, win, k0, ha16, ha27, acc, dirty);
+                    else if (pat == 1) tube_mode<1, PW>(smem, win, k0, ha16, ha27, acc, dirty);
+                    else tube_mode<2, PW>(smem, win, k0, ha16, ha27, acc, dirty);
                 }
                 if constexpr (OUT == kOutPackedRGBU4) {
 #pragma unroll
@@ -560,7 +557,7 @@ __global__ void __launch_bounds__(TW *TH) stage_tube_kernel(StageArgs a, BandArg
                     uint32_t o[4];
                     finish_channel<4, OUT>(a, acc, n, c, y, x, o);
                 }
-                if constexpr (!FLAGGED) dmask |= (dirty != 0u ? 1u : 0u) << c;
+                dmask |= (dirty != 0u ? 1u : 0u) << c;
             }
             if constexpr (OUT == kOutPackedRGBU4) store_rgb<4>(a, n, y, x, o0, o1, o2);
             // dirty samples (pixel, channel) go on the fix-up list: one atomic per wave and channel (rare), compacted by lane rank
@@ -727,9 +724,7 @@ const char *stage_tube_name(int out_mode) {
 
 template <int OUT>
 static hipError_t launch_tube_t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
-    auto kern_t = stage_tube_kernel<OUT, KB_TW, KB_TH, true>;
-    auto kern_f = stage_tube_kernel<OUT, KB_TW, KB_TH, false>;
-    auto kern = a.site_flags ? kern_t : kern_f;
+    auto kern = stage_tube_kernel<OUT, KB_TW, KB_TH>;
     {
         const hipError_t e = raise_lds_limit((const void *)kern, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -1174,7 +1169,7 @@ static bool tube2_counts(const StageArgs &a, int (&cnt)[3]) {
 bool stage_tube2_supported(const StageArgs &a) {
     int cnt[3];
     // the float epilogue must be exact for the divisor (StageArgs::use_f32, proven at configure time), the bias the numerator bias of a final stage
-    return a.C <= 3 && a.M <= kMaxTube2Modes && a.site_flags == nullptr && tube2_counts(a, cnt) && cnt[0] && cnt[1] && cnt[2] && a.use_f32 &&
+    return a.C <= 3 && a.M <= kMaxTube2Modes && tube2_counts(a, cnt) && cnt[0] && cnt[1] && cnt[2] && a.use_f32 &&
            a.bias_num == 0;
 }
 

@@ -38,5 +38,13 @@ PY
 timeout -k 10 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"
 timeout -k 10 200 python bench.py --config 4 > $O/${TAG}_config4.json 2>> $O/${TAG}_bench.err; echo "config4 rc=$?"
 timeout -k 10 300 python bench.py --config 5 --frames 8 > $O/${TAG}_config5.json 2>> $O/${TAG}_bench.err; echo "config5 rc=$?"
+timeout -k 10 400 python bench.py --batch rolled --skip-other --skip-strips --cpu-crop 0 > $O/${TAG}_bench_rolled_batch.json 2>> $O/${TAG}_bench.err; echo "bench (rolled batch) rc=$?"
+[ -x build/ubench_lds_atomic ] && timeout -k 10 120 build/ubench_lds_atomic > $O/${TAG}_ubench_lds_atomic.txt 2>&1
+( cd /tmp && export TMPDIR=/tmp && for d in real noise; do
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_${TAG}_$d -- python $R/bench.py --dist $d --cpu-crop 0 --steps 4 --warmup 2 --skip-other --skip-strips > $O/stats_${TAG}_$d.log 2>&1
+    find $O/stats_${TAG}_$d -name '*kernel_stats.csv' -exec cp {} $O/${TAG}_kernel_stats_$d.csv \;
+  done )
+timeout -k 10 600 python tools/fuzz_parity.py --cases 1000 --seed 303 > $O/${TAG}_fuzz_parity.jsonl 2>&1; echo "fuzz parity rc=$?"
+timeout -k 10 300 python tools/fuzz_finetune.py --cases 150 --seed 303 > $O/${TAG}_fuzz_finetune.jsonl 2>&1; echo "fuzz finetune rc=$?"
 cp profiles/kernel_counters.json profiles/hbm_traffic.json profiles/valu_issue.json profiles/finetune_counters.json $O/ 2>/dev/null
 echo done
