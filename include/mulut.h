@@ -169,7 +169,8 @@ int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int
  *   rows in flight under the current pass's multiply-adds, one 16x4 tile per wave, no workgroup barrier), 0 = stage_tube_kernel.
  * "detail_kernel": the detailed tiles of the hybrid: 0 (default) = anchor slabs in LDS (samples grouped by anchor MSB on the
  *   device, stage_slab_kernel; taken when the stage input is planar, < 2^28 bytes, <= 3 modes), 1 = full-table gather kernel.
- * "fix_kernel": the fix-up of the tube kernels' work list: 0 (default) = one pass per lane, 1 = one entry per thread.
+ * "fix_kernel": the fix-up of the tube kernels' work list: 0 (default) = one pass per lane, 1 = one entry per thread,
+ *               2 = one pass per lane with the list walk software-pipelined.
  * "stat_from_first_stage": 1 (default) = when the final stage reads what a content-routing first-stage launch of the same
  *   call wrote, its per-tile statistic looks only at the tiles that launch marked detailed; 0 = at every tile.
  * "hybrid_oob_per_1024": tile threshold of the hybrid (sites out of band per 1024, default 128).

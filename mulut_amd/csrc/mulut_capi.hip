@@ -823,8 +823,8 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
         ctx->stat_from_k1 = value;
         return MULUT_OK;
     }
-    if (!strcmp(key, "fix_kernel")) {      // fix-up of the u == 4 tube kernels: 0 = one pass per lane, 1 = one entry per thread
-        if (value < 0 || value > 1) return MULUT_EINVAL;
+    if (!strcmp(key, "fix_kernel")) {      // fix-up of the u == 4 tube kernels: 0 = one pass per lane, 1 = one entry per thread, 2 = one pass per lane with the list walk pipelined
+        if (value < 0 || value > 2) return MULUT_EINVAL;
         ctx->fix_variant = value;
         return MULUT_OK;
     }

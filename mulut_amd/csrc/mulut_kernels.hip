@@ -706,11 +706,119 @@ __global__ void __launch_bounds__(256) stage_up_fix2_kernel(StageArgs a) {
     }
 }
 
-// variant (tuning "fix_kernel"): 0 = one pass per lane (stage_up_fix2_kernel), 1 = one entry per thread (stage_up_fix_kernel)
+// stage_up_fix2_kernel with the list walk software-pipelined: an entry costs three dependent trips to memory (the entry, its
+// pixels, the table rows); here a group reads the entry two iterations ahead and the pixels one iteration ahead, so that what is
+// left per iteration is the trip for the rows.  (An experiment: no faster than stage_up_fix2_kernel, see launch_stage_up_fix.)  Same arithmetic, same order of the
+// integer sums.  An entry that names every channel (border columns of the detailed-tile path) takes its first channel through
+// the pipeline and the others in a plain loop.
+__global__ void __launch_bounds__(256) stage_up_fix3_kernel(StageArgs a) {
+    __shared__ int s_sum[16][16];
+    const uint32_t count = *a.fix_count;
+    const int grp = (int)(threadIdx.x >> 4), ln = (int)(threadIdx.x & 15);
+    const int ylo = imax(a.oy0 - kHalo, 0), yhi = imin(a.oy1 + kHalo, a.H) - 1;
+    const int unbias = 128 * kQ * 4 * a.M - a.bias_num;
+    const uint32_t stride = gridDim.x * 16u;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;      // (a pixel id never has all of its low 30 bits set: N H W < 2^30)
+    struct Pix { int x, y, n, va, v[3]; };
+    auto decode = [&](uint32_t ent, int &x, int &y, int &n) {
+        const uint32_t id = ent & 0x3FFFFFFFu;
+        x = (int)(id % (uint32_t)a.W); y = (int)((id / (uint32_t)a.W) % (uint32_t)a.H); n = (int)(id / ((uint32_t)a.W * (uint32_t)a.H));
+    };
+    // the anchor and this lane's three neighbours (pass ln: mode ln / 4, rotation ln % 4) of channel c of an entry
+    auto fetch = [&](uint32_t ent, int c, Pix &p) {
+        if (ent == kNone) return;
+        decode(ent, p.x, p.y, p.n);
+        auto px = [&](int dy, int dx) {
+            const int gy = imin(imax(p.y + dy, ylo), yhi), gx = imin(imax(p.x + dx, 0), a.W - 1);
+            return (int)*view_addr(a.in, p.n, c, gy, gx);
+        };
+        p.va = px(0, 0);
+        if (ln < 4 * a.M) {
+            const int m = ln >> 2, r = ln & 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int dy, dx;
+                sample_offset(r, a.di[m][k], a.dj[m][k], dy, dx);
+                p.v[k] = px(dy, dx);
+            }
+        }
+    };
+    // passes pass0, pass0 + 16, ... of the sample whose pixels for pass pass0 are in p (later passes fetch their own), then the byte
+    auto finish = [&](const Pix &p, int c) {
+        s_sum[grp][ln] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int q = ln; q < 4 * a.M; q += 16) {
+            const int m = q >> 2, r = q & 3;
+            int v[3] = {p.v[0], p.v[1], p.v[2]};
+            if (q != ln) {      // more than four modes: the passes beyond the sixteenth
+                auto px = [&](int dy, int dx) {
+                    const int gy = imin(imax(p.y + dy, ylo), yhi), gx = imin(imax(p.x + dx, 0), a.W - 1);
+                    return (int)*view_addr(a.in, p.n, c, gy, gx);
+                };
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    int dy, dx;
+                    sample_offset(r, a.di[m][k], a.dj[m][k], dy, dx);
+                    v[k] = px(dy, dx);
+                }
+            }
+            int idx[5], w[5];
+            simplex4(p.va, v[0], v[1], v[2], idx, w);
+            const uint4 *tab = (const uint4 *)a.lut[m];
+            uint32_t row[5][4];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const uint4 t = tab[idx[j]];
+                row[j][0] = t.x; row[j][1] = t.y; row[j][2] = t.z; row[j][3] = t.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int sum = 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) sum += w[j] * (int)((row[j][e >> 2] >> (8 * (e & 3))) & 0xFFu);
+                const int pos = r == 0 ? e : r == 1 ? (e & 3) * 4 + 3 - (e >> 2) : r == 2 ? 15 - e : (3 - (e & 3)) * 4 + (e >> 2);
+                atomicAdd(&s_sum[grp][pos], sum);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t b = rhe_clip_u8(s_sum[grp][ln] - unbias, a.div);
+        *const_cast<uint8_t *>(view_addr(a.out, p.n, c, p.y * 4 + (ln >> 2), p.x * 4 + (ln & 3))) = (uint8_t)b;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // sums read before the next round clears them
+    };
+    auto first_channel = [&](uint32_t ent) { return (ent >> 30) == 3u ? 0 : (int)(ent >> 30); };
+
+    uint32_t i = blockIdx.x * 16u + (uint32_t)grp;
+    uint32_t ent_cur = i < count ? a.fix_list[i] : kNone;
+    uint32_t ent_nxt = i + stride < count && i + stride >= i ? a.fix_list[i + stride] : kNone;
+    Pix cur, nxt;
+    cur.x = cur.y = cur.n = cur.va = 0; cur.v[0] = cur.v[1] = cur.v[2] = 0;
+    nxt = cur;
+    if (ent_cur != kNone) fetch(ent_cur, first_channel(ent_cur), cur);
+    while (ent_cur != kNone) {      // uniform in the group
+        const uint32_t i2 = i + 2u * stride;
+        const uint32_t ent_nn = (i2 < count && i2 >= i) ? a.fix_list[i2] : kNone;
+        if (ent_nxt != kNone) fetch(ent_nxt, first_channel(ent_nxt), nxt);
+        const int c0 = first_channel(ent_cur);
+        finish(cur, c0);
+        if ((ent_cur >> 30) == 3u)
+            for (int c = 1; c < a.C; ++c) {
+                Pix p;
+                p.v[0] = p.v[1] = p.v[2] = 0;
+                fetch(ent_cur, c, p);
+                finish(p, c);
+            }
+        ent_cur = ent_nxt; cur = nxt; ent_nxt = ent_nn; i += stride;
+    }
+}
+
+// variant (tuning "fix_kernel"): 0 = one pass per lane (stage_up_fix2_kernel), 1 = one entry per thread (stage_up_fix_kernel),
+// 2 = one pass per lane with the list walk pipelined (stage_up_fix3_kernel: measured equal to 0 within noise on every content --
+// the walk is not what the kernel waits for -- kept as a variant)
 hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st, int variant) {
     if (a.C > 3 || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(4 * num_cus)), block(256);
     if (variant == 0) hipLaunchKernelGGL(stage_up_fix2_kernel, dim3((unsigned)(8 * num_cus)), block, 0, st, a);
+    else if (variant == 2) hipLaunchKernelGGL(stage_up_fix3_kernel, dim3((unsigned)(8 * num_cus)), block, 0, st, a);
     else if (out_mode == kOutPlanarU4) hipLaunchKernelGGL((stage_up_fix_kernel<kOutPlanarU4>), grid, block, 0, st, a);
     else if (out_mode == kOutPackedRGBU4 && a.C == 3) hipLaunchKernelGGL((stage_up_fix_kernel<kOutPackedRGBU4>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((stage_up_fix_kernel<kOutGeneric>), grid, block, 0, st, a);

@@ -357,7 +357,7 @@ def test_hybrid_final_stage_variants_agree_and_capture(eng, shipped_luts):
             assert torch.equal(eng.pipeline(x), want), (pipelined, sel, thr)
     eng.set_tuning("tube_pipelined", 1).set_tuning("hybrid_oob_per_1024", 128).set_tuning("final_stage_kernel", 0)
     for key in ("stat_from_first_stage", "detail_kernel", "fix_kernel"):       # the routing / work-list options of the default path
-        for val in (0, 1):
+        for val in ((0, 1, 2) if key == "fix_kernel" else (0, 1)):
             eng.set_tuning(key, val)
             assert torch.equal(eng.pipeline(x), want), (key, val)
     eng.set_tuning("stat_from_first_stage", 1).set_tuning("detail_kernel", 0).set_tuning("fix_kernel", 0)

@@ -65,7 +65,7 @@ def main():
         e = MuLUTEngine(0).configure(stages, modes, scale, 4).set_lut_dict(luts)
         e.set_tuning("final_stage_kernel", int(rng.choice([0, 1, 5, 6])))
         e.set_tuning("tube_pipelined", int(rng.integers(0, 4) != 0))      # mostly the hand-scheduled kernel (the default)
-        e.set_tuning("fix_kernel", int(rng.integers(0, 4) == 0))
+        e.set_tuning("fix_kernel", int(rng.choice([0, 0, 0, 1, 2])))      # mostly one pass per lane (the default)
         e.set_tuning("hybrid_oob_per_1024", int(rng.choice([0, 16, 128, 512, 1024])))
         e.set_tuning("first_stage_kernel", int(rng.choice([0, 2, 3])))
         e.set_tuning("detail_kernel", int(rng.integers(0, 4) == 0))      # mostly the anchor-slab kernel (the default)
