@@ -154,8 +154,15 @@ def test_more_shapes_vs_cpu_oracle(tmp_path, stages, modes, scale, shape, kind):
     yg = net(xg)
     torch.nn.functional.mse_loss(yg, torch.from_numpy(tgt).cuda()).backward()
     assert np.abs(yg.detach().cpu().numpy() - yc.detach().numpy()).max() <= 1e-5
-    big = shape[0] * shape[2] * shape[3] > 10000      # many float atomics per table row: summation-order noise grows with the count
-    assert np.allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=2e-4, atol=1e-6 if big else 1e-7)
+    # Gradients are sums of up to ~10^5 float32 terms per table row whose order is not fixed (float atomics, group-private partial
+    # sums): the bar is norm-wise, max |g - ref| <= 2e-5 max |ref| -- measured 6e-6 on the bs-256 batches (tools/ft_err_probe.py),
+    # 50x tighter than the rtol 1e-3 / atol 1e-5 this test used through round 2 -- and element-wise rtol 5e-5 where the
+    # reference is not itself a cancellation (|ref| > 1 % of its maximum; measured 1.4e-5)
+    def close(g, r, what):
+        scale = max(float(np.abs(r).max()), 1e-30)
+        assert float(np.abs(g - r).max()) <= 2e-5 * scale, (what, float(np.abs(g - r).max()), scale)
+        sig = np.abs(r) > 0.01 * scale
+        assert np.allclose(g[sig], r[sig], rtol=5e-5, atol=0.0), what
+    close(xg.grad.cpu().numpy(), xc.grad.numpy(), "gx")
     for k, w in wcpu.items():
-        g = getattr(net, "weight_" + k).grad.cpu().numpy()
-        assert np.allclose(g, w.grad.numpy(), rtol=1e-3 if big else 2e-4, atol=1e-5 if big else 1e-7), k
+        close(getattr(net, "weight_" + k).grad.cpu().numpy(), w.grad.numpy(), k)
