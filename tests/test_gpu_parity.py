@@ -531,3 +531,27 @@ def test_config3_strips_on_4k_lr_frame_two_ranks():
         p.join(120)
         assert p.exitcode == 0
     assert got[0] == (0, True, (8640, 15360, 3)) and got[1][1]
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_rehearsal(tmp_path):
+    """bench.py's N > 1 path end to end on one device: two ranks under torchrun (gloo through host memory stands in for RCCL, which
+    refuses two ranks on one GPU), frames per rank + the config-3 legs (single root and rotating roots), one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MULUT_NO_BUILD="1", MULUT_BENCH_BACKEND="gloo")
+    port = 29500 + (os.getpid() % 400)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--frames", "2", "--steps", "2", "--warmup", "1",
+           "--cpu-crop", "0", "--skip-other", "--lr-h", "270", "--lr-w", "480", "--strip-frames", "2"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    sg = rec["config"]["strips_gather"]
+    assert sg["ranks_in_group"] == 2 and sg["single_root"]["value"] > 0 and sg["rotate"]["value"] > 0
+    assert sg["rotate"]["max_bytes_into_one_rank_per_step"] * 2 == sg["single_root"]["max_bytes_into_one_rank_per_step"]
