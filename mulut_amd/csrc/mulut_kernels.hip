@@ -864,16 +864,8 @@ hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode
 // The mode list is a template parameter (PATS = M | p0 << 2 | p1 << 4 | p2 << 6): every neighbour offset and band offset is
 // an immediate.  Instantiated for the mode strings launch_stage_tube2 lists; the others take stage_tube_kernel.
 // ------------------------------------------------------------------------------------------
-#if defined(MULUT_VARIANT_t2dbg1)
-#include "mulut_tube2_asm_dbg1.inc"
-#elif defined(MULUT_VARIANT_t2dbg2)
-#include "mulut_tube2_asm_dbg2.inc"
-#elif defined(MULUT_VARIANT_t2dbg3)
-#include "mulut_tube2_asm_dbg3.inc"
-#elif defined(MULUT_VARIANT_t2dbg4)
-#include "mulut_tube2_asm_dbg4.inc"
-#elif defined(MULUT_VARIANT_t2dbg5)
-#include "mulut_tube2_asm_dbg5.inc"
+#if defined(MULUT_TUBE2_ASM_INC)      /* timing-only generations of the blocks (tools/experiments/tube2_timing, TUBE2_DEBUG=1..5 of the generator) */
+#include MULUT_TUBE2_ASM_INC
 #else
 #include "mulut_tube2_asm.inc"
 #endif

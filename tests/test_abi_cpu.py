@@ -147,3 +147,13 @@ def test_tube2_private_registers_stay_private(tmp_path):
                     bad.append((name, line.strip()))
     assert kernels == 3, kernels          # generic, planar, rgb
     assert not bad, bad[:5]
+
+
+def test_tube2_blocks_match_their_generator(tmp_path):
+    """mulut_tube2_asm.inc is generated (tools/gen_tube2_asm.py) and committed: the two must not drift apart."""
+    import subprocess
+    import sys
+    out = str(tmp_path / "gen.inc")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TUBE2_")}
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_tube2_asm.py"), out], env=env, stdout=subprocess.DEVNULL)
+    assert open(out).read() == open(os.path.join(ROOT, "mulut_amd", "csrc", "mulut_tube2_asm.inc")).read()

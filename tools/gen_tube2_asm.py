@@ -6,12 +6,12 @@ The kernel keeps the five table rows of a pass (5 x 32 bytes per lane) in VGPRs 
 allocates can live there.  A block is one pass: per row  s_waitcnt -> 8 v_pk_mad_u16 -> the two ds_read_b128 that
 refill the row's registers with the NEXT pass's row.  LDS returns in order, so the waits are plain counts.
 
-    python tools/gen_tube2_asm.py            (re-run after changing the register map; the output is committed)
+    python tools/gen_tube2_asm.py [out]      (re-run after changing the register map; the output is committed)
 """
 import os
 import sys
 
-DEBUG = int(os.environ.get("TUBE2_DEBUG", "0"))      # timing / debugging builds (MULUT_VARIANT_t2dbgN): 1: s_nop 4 after every wait, 2: every wait drains (lgkmcnt(0)),
+DEBUG = int(os.environ.get("TUBE2_DEBUG", "0"))      # timing / debugging builds (written to tools/experiments/tube2_timing; -DMULUT_TUBE2_ASM_INC selects one): 1: s_nop 4 after every wait, 2: every wait drains (lgkmcnt(0)),
 # 3: s_nop 4 at the end of every block, 4: no row reads (wrong results: VALU-only time), 5: no MACs (wrong results: LDS-only time)
 
 WAIT_GROUPS = [[int(c) for c in g] for g in os.environ.get("TUBE2_WAITS", "012,34").split(",")]
@@ -185,7 +185,13 @@ def main():
     block(ql, True, 0, False, 0, "B", "A")
     assert ql.q == [], ql.q
     out.append(cstr("TUBE2_ASM_B_LAST", ql.out))
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mulut_amd", "csrc", "mulut_tube2_asm%s.inc" % ("_dbg%s" % os.environ.get("TUBE2_TAG", DEBUG) if (DEBUG or os.environ.get("TUBE2_TAG")) else ""))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if DEBUG or os.environ.get("TUBE2_TAG"):     # timing-only generations: built with -DMULUT_TUBE2_ASM_INC='"<path>"'
+        path = os.path.join(root, "tools", "experiments", "tube2_timing", "mulut_tube2_asm_dbg%s.inc" % os.environ.get("TUBE2_TAG", DEBUG))
+    else:
+        path = os.path.join(root, "mulut_amd", "csrc", "mulut_tube2_asm.inc")
+    if len(sys.argv) > 1:       # another destination (tests/test_abi_cpu.py compares it with the committed file)
+        path = sys.argv[1]
     with open(path, "w") as f:
         f.write("\n".join(out))
     print("wrote", path)
