@@ -1057,6 +1057,8 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
     const unsigned long long t_first = __builtin_amdgcn_s_memtime(), r_first = __builtin_amdgcn_s_memrealtime();
     uint32_t t_prev = (uint32_t)t_first, t_ph0 = 0, t_ph1 = 0, t_ph2 = 0, t_ph3 = 0, t_ph4 = 0, t_ph5 = 0;      // wave-uniform (scalar registers)
 #define T2_STAMP(PH) do { const uint32_t t_now = (uint32_t)__builtin_amdgcn_s_memtime(); t_ph##PH += t_now - t_prev; t_prev = t_now; } while (0)
+#elif defined(MULUT_T2_MARKERS)     /* ISA analysis only (tools/asm_stats.sh ... -DMULUT_T2_MARKERS): phase boundaries as comments in the assembly */
+#define T2_STAMP(PH) asm volatile("; MULUT_T2_PHASE_END " #PH)
 #else
 #define T2_STAMP(PH) do { } while (0)
 #endif
