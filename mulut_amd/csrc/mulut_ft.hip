@@ -188,6 +188,7 @@ __device__ __forceinline__ void lds_adds_done() { asm volatile("s_waitcnt lgkmcn
 //   u == 1: one float per item: items inside the tube (991 rows, the ones smooth content uses) are summed into a
 //           per-workgroup LDS copy of the tube band with ds_add_f32 and flushed once per workgroup as contiguous
 //           atomics; items outside it go to global memory directly.
+constexpr int kFtGxFloats = 2048;      // LDS rows of the input gradient per workgroup (ft_stage_bwd)
 template <int U>
 __device__ __forceinline__ int eo_of_elem(int r, int e) {      // block position whose table element is e under rotation r (inverse of row_elem)
     return r == 0 ? e : r == 1 ? U * (e % U) + (U - 1 - e / U) : r == 2 ? U * U - 1 - e : U * (U - 1 - e % U) + e / U;
@@ -200,6 +201,7 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
     __shared__ int s_idx[5][NT];
     __shared__ float s_wq[5][NT];
     __shared__ float s_band[U == 1 ? kMaxFtModes * kTubeSlots : 1];
+    __shared__ float s_gx[kFtGxFloats];
     const long long nsite = (long long)a.B * a.C * a.H * a.W;
     const long long s = (long long)blockIdx.x * NT + threadIdx.x;
     const bool valid = s < nsite;
@@ -208,6 +210,15 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
     const long long bc = sc / ((long long)a.W * a.H);
     const float *plane = a.x + bc * a.H * a.W;
     float *gplane = a.gx + bc * a.H * a.W;
+    // The input gradient gets 48 adds per site, into pixels at most two rows away.  The workgroup's sites are consecutive, so their
+    // targets lie in a few consecutive rows of the stacked image (planes one under the other = the memory layout of gx): those rows
+    // are summed in LDS and added to memory once per workgroup (memory-side float atomics were 0.6 ms of each backward kernel at
+    // bs 256 x 48 x 48).  Crops are small in fine-tuning (48 x 48); when the rows do not fit, the adds go to memory as before.
+    const long long gx_r0 = (long long)blockIdx.x * NT / a.W - 2;
+    const long long gx_r1 = (((long long)blockIdx.x * NT + NT - 1 < nsite ? (long long)blockIdx.x * NT + NT - 1 : nsite - 1)) / a.W + 2;
+    const int gx_n = (int)((gx_r1 - gx_r0 + 1) * a.W <= kFtGxFloats ? (gx_r1 - gx_r0 + 1) * a.W : 0);      // 0: does not fit
+    const int gx_off = (int)((bc * a.H - gx_r0) * a.W);       // index of a pixel in s_gx = its index in the plane + this
+    for (int i = threadIdx.x; i < gx_n; i += NT) s_gx[i] = 0.0f;
     if constexpr (U == 1)
         for (int i = threadIdx.x; i < a.M * kTubeSlots; i += NT) s_band[i] = 0.0f;
     float g[EL];
@@ -224,7 +235,7 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
             s_g[threadIdx.x][eo] = g[eo];
         });
     }
-    if constexpr (U == 1) __syncthreads();      // the band must be zero before any wave adds into it (no other barrier precedes the adds)
+    __syncthreads();      // the band and the gradient rows must be zero before any wave adds into them
     for (int m = 0; m < a.M; ++m) {
         const float *tab = a.w[m];
         float *gtab = a.gw[m];
@@ -260,7 +271,10 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {   // d/d f of rank j+1 = (p_{j+1} - p_j) . g / q
                 const float df = (dsum[j + 1] - dsum[j]) / (float)kQ;
-                if (df != 0.0f) atomicAdd(&gplane[p.src[j]], df);
+                if (df != 0.0f) {
+                    if (gx_n) lds_add_f32(&s_gx[p.src[j] + gx_off], df);
+                    else atomicAdd(&gplane[p.src[j]], df);
+                }
             }
             if constexpr (U > 1) {
                 __syncthreads();
@@ -278,9 +292,14 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
             }
         }
     }
+    lds_adds_done();
+    __syncthreads();
+    for (int i = threadIdx.x; i < gx_n; i += NT) {      // the gradient rows: the stacked image IS gx's layout
+        const float v = s_gx[i];
+        const long long r = gx_r0 + i / a.W;
+        if (v != 0.0f && r >= 0 && r < (long long)a.B * a.C * a.H) atomicAdd(&a.gx[r * a.W + i % a.W], v);
+    }
     if constexpr (U == 1) {
-        lds_adds_done();
-        __syncthreads();
         // flush the workgroup's tube-band sums: contiguous floats, a wave adds 256 bytes at a time
         for (int m = 0; m < a.M; ++m) {
             float *gtab = a.gw[m];
@@ -317,7 +336,8 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
 #define MULUT_FT_ABL 0      // timing-only ablations (tools/ab_bench.py variants ftabl1..5): never in the product build
 #endif
 constexpr int kFtB4Sites = 512, kFtB4Groups = kFtB4Sites / 16;
-constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Groups * 16 * 16 * 4 + 5 * kFtB4Sites * 8;
+constexpr int kFtB4GxFloats = 1536;      // rows of the input gradient summed in LDS (as in ft_stage_bwd)
+constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Groups * 16 * 16 * 4 + 5 * kFtB4Sites * 8 + kFtB4GxFloats * 4;
 static_assert(kFtB4Lds <= 160 * 1024, "ft_stage_bwd4: LDS");
 
 __device__ __forceinline__ float ft_sum16(float v) {      // sum over the 16 lanes of a DPP row; every lane gets it
@@ -340,6 +360,7 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
     float (*s_g)[17] = (float (*)[17])(ft_smem + kTubeSlots * 16 * 4);
     float *s_cache = (float *)(ft_smem + kTubeSlots * 16 * 4 + NT * 17 * 4);
     FtItem *s_item = (FtItem *)(s_cache + NG * 256);      // [5][NT]
+    float *s_gx = (float *)(s_item + 5 * NT);             // [kFtB4GxFloats]
     // a group's 16 sites are a 4x4 block of one plane (lane = 4 * row + column): neighbours in both directions share MSB cells, so
     // the group's cache sees fewer cell changes than with 16 sites along a row; lanes beyond the plane shadow its last site
     const int e = (int)threadIdx.x & 15, grp = (int)threadIdx.x >> 4, first = grp * 16, gshift = (int)threadIdx.x & 48;
@@ -353,6 +374,16 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
     const int y = imin(y0, a.H - 1), x = imin(x0, a.W - 1);
     const float *plane = a.x + bc * a.H * a.W;
     float *gplane = a.gx + bc * a.H * a.W;
+    // input gradient rows in LDS (see ft_stage_bwd): the workgroup's blocks are consecutive in block order, i.e. they lie in a few
+    // consecutive block rows of the stacked image (planes one under the other, each padded to 4 bh rows); two more rows on either side
+    const int Hp = 4 * bh;
+    const long long gby0 = (long long)blockIdx.x * NG / bw;
+    const long long gby1 = ((long long)blockIdx.x * NG + NG - 1 < nblock ? (long long)blockIdx.x * NG + NG - 1 : nblock - 1) / bw;
+    const long long gx_r0 = 4 * gby0 - 2;
+    const int gx_rows = (int)(4 * (gby1 - gby0 + 1) + 4);
+    const int gx_n = (long long)gx_rows * a.W <= kFtB4GxFloats ? gx_rows * a.W : 0;      // 0: does not fit, adds go to memory
+    const int gx_off = (int)((bc * Hp - gx_r0) * a.W);        // index of a pixel in s_gx = its index in the plane + this
+    for (int i = threadIdx.x; i < gx_n; i += NT) s_gx[i] = 0.0f;      // (the first barrier of the mode loop comes before any add)
     {
         float pred[EL];
 #if MULUT_FT_ABL == 2
@@ -457,7 +488,10 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
                 const float cur = s_item[j * NT + threadIdx.x].wq;
                 const float df = (cur - dprev) / (float)kQ;
 #if MULUT_FT_ABL != 3
-                if (valid && df != 0.0f) atomicAdd(&gplane[src[j - 1]], df);
+                if (valid && df != 0.0f) {
+                    if (gx_n) lds_add_f32(&s_gx[src[j - 1] + gx_off], df);
+                    else atomicAdd(&gplane[src[j - 1]], df);
+                }
 #else
                 if (valid && df == 123.456f) atomicAdd(&gplane[src[j - 1]], df);
 #endif
@@ -481,6 +515,15 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
                 if (v != 0.0f) atomicAdd(&gtab[(long long)(A * kStrideA + B * kStrideB + C * kStrideC + D) * EL + e], v);
             }
         __syncthreads();
+    }
+    // (every add into s_gx was drained before the last mode's barrier)
+    for (int i = threadIdx.x; i < gx_n; i += NT) {
+        const float v = s_gx[i];
+        const long long r = gx_r0 + i / a.W;
+        if (v == 0.0f || r < 0) continue;
+        const long long pl = r / Hp;
+        const int yy = (int)(r % Hp);
+        if (pl < (long long)a.B * a.C && yy < a.H) atomicAdd(&a.gx[(pl * a.H + yy) * a.W + i % a.W], v);
     }
 }
 
