@@ -236,6 +236,7 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
         });
     }
     __syncthreads();      // the band and the gradient rows must be zero before any wave adds into them
+    float own = 0.0f;
     for (int m = 0; m < a.M; ++m) {
         const float *tab = a.w[m];
         float *gtab = a.gw[m];
@@ -271,7 +272,8 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {   // d/d f of rank j+1 = (p_{j+1} - p_j) . g / q
                 const float df = (dsum[j + 1] - dsum[j]) / (float)kQ;
-                if (df != 0.0f) {
+                if (p.src[j] == y * a.W + x) own += df;      // the site's own pixel is a key of every pass: summed here, added once
+                else if (df != 0.0f) {
                     if (gx_n) lds_add_f32(&s_gx[p.src[j] + gx_off], df);
                     else atomicAdd(&gplane[p.src[j]], df);
                 }
@@ -291,6 +293,10 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
                 __syncthreads();
             }
         }
+    }
+    if (own != 0.0f) {
+        if (gx_n) lds_add_f32(&s_gx[y * a.W + x + gx_off], own);
+        else atomicAdd(&gplane[y * a.W + x], own);
     }
     lds_adds_done();
     __syncthreads();
@@ -381,7 +387,13 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
     const long long gby1 = ((long long)blockIdx.x * NG + NG - 1 < nblock ? (long long)blockIdx.x * NG + NG - 1 : nblock - 1) / bw;
     const long long gx_r0 = 4 * gby0 - 2;
     const int gx_rows = (int)(4 * (gby1 - gby0 + 1) + 4);
-    const int gx_n = (long long)gx_rows * a.W <= kFtB4GxFloats ? gx_rows * a.W : 0;      // 0: does not fit, adds go to memory
+    // (measured: in THIS kernel the LDS pipeline is the busy one -- cache traffic, evictions -- and the 48 ds_add_f32 per site cost more
+    // than the memory-side atomics they replace, 2.38 against 2.27 ms; in ft_stage_bwd they halve the kernel.  MULUT_FT_B4_GX_LDS=1 builds
+    // the LDS variant.)
+#ifndef MULUT_FT_B4_GX_LDS
+#define MULUT_FT_B4_GX_LDS 0
+#endif
+    const int gx_n = (MULUT_FT_B4_GX_LDS && (long long)gx_rows * a.W <= kFtB4GxFloats) ? gx_rows * a.W : 0;      // 0: adds go to memory
     const int gx_off = (int)((bc * Hp - gx_r0) * a.W);        // index of a pixel in s_gx = its index in the plane + this
     for (int i = threadIdx.x; i < gx_n; i += NT) s_gx[i] = 0.0f;      // (the first barrier of the mode loop comes before any add)
     {
@@ -401,6 +413,7 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
         });
     }
     float *cache = s_cache + grp * 256;      // [16 entries][16 elements]
+    float own = 0.0f;
     for (int m = 0; m < a.M; ++m) {
         const float *tab = a.w[m];
         float *gtab = a.gw[m];
@@ -488,7 +501,8 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
                 const float cur = s_item[j * NT + threadIdx.x].wq;
                 const float df = (cur - dprev) / (float)kQ;
 #if MULUT_FT_ABL != 3
-                if (valid && df != 0.0f) {
+                if (src[j - 1] == y * a.W + x) own += df;      // the site's own pixel is a key of every pass: summed here, added once
+                else if (valid && df != 0.0f) {
                     if (gx_n) lds_add_f32(&s_gx[src[j - 1] + gx_off], df);
                     else atomicAdd(&gplane[src[j - 1]], df);
                 }
@@ -516,6 +530,7 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
             }
         __syncthreads();
     }
+    if (valid && own != 0.0f) atomicAdd(&gplane[y * a.W + x], own);
     // (every add into s_gx was drained before the last mode's barrier)
     for (int i = threadIdx.x; i < gx_n; i += NT) {
         const float v = s_gx[i];
