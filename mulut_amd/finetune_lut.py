@@ -9,7 +9,7 @@ rigid augmentation (sr/data.py:96-124), and writes ``LUT_ft_x{scale}_{interval}b
 Training pairs: ``{trainDir}/HR/<stem>.png`` with ``{trainDir}/LR/X{scale}/<stem>x{scale}.png`` (DIV2K layout) or
 ``{trainDir}/LR_bicubic/X{scale}/<stem>.png`` (benchmark layout).  ``valid_steps`` is the reference's validation loop
 (:23-65): every ``--valStep`` iterations (and at iteration 1) each benchmark image goes through the module, the result is
-saved as ``{valoutDir}/{dataset}/{stem}_lutft.png`` and Y-PSNR / SSIM are averaged per dataset -- computed on the device
+saved as ``{valoutDir}/{dataset}/{last '_'-token of the stem}_lutft.png`` (the reference's naming) and Y-PSNR / SSIM are averaged per dataset -- computed on the device
 (``mulut_eval_y``), logged with the reference's line.
 """
 import argparse
@@ -107,7 +107,9 @@ def valid_steps(net, opt, it, log=print):
                     raise RuntimeError(lib.mulut_strerror(rc).decode())
                 psnrs.append(ps.value)
                 ssims.append(ss.value)
-                Image.fromarray(pred_u8.cpu().numpy()).save(os.path.join(out_dir, '{}_lutft.png'.format(fn[:-4])))
+                # the reference names the file after the LAST '_'-separated token of "{dataset}_{stem}" (sr/3_finetune_lut.py:41,61):
+                # Urban100's img_001.png becomes 001_lutft.png -- kept, a drop-in writes the same names
+                Image.fromarray(pred_u8.cpu().numpy()).save(os.path.join(out_dir, '{}_lutft.png'.format((ds + '_' + fn[:-4]).split('_')[-1])))
             if psnrs:
                 results[ds] = (float(np.mean(psnrs)), float(np.mean(ssims)))
                 log('Iter {} | Dataset {} | AVG PSNR: {:02f}, AVG: SSIM: {:04f}'.format(it, ds, results[ds][0], results[ds][1]))
