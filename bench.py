@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=128, help="LR frames per GPU per step (128 = 4 x 32 draws: a 20-step timed region lasts ~0.6 s, long enough for an external busy sampler to see it)")
+    ap.add_argument("--launch-frames", type=int, default=32, help="frames per mulut_pipeline call (a step makes frames / launch-frames calls)")
     ap.add_argument("--batch", choices=("draws", "rolled"), default="draws", help="draws: every frame its own draw of the distribution; rolled: rounds 1-2's batch")
     ap.add_argument("--lr-h", type=int, default=1080)
     ap.add_argument("--lr-w", type=int, default=1920)
@@ -244,13 +245,26 @@ def main():
             print(json.dumps(rec), flush=True)
         return
 
+    # A step takes its F frames through the library in calls of LF frames: one mulut_pipeline call is one launch of every kernel, and the
+    # device work lists of the detailed-tile path address at most 256 MB of stage input per launch (43 frames of 1080p: DESIGN section 6).
+    LF = min(F, args.launch_frames)
+    if F % LF:
+        raise SystemExit("--frames must be a multiple of --launch-frames")
+    calls = F // LF
     eng = MuLUTEngine(local).configure(STAGES, MODES, SCALE, 4).set_lut_dict(luts)
-    eng.reserve(F, H, W, 3)
+    eng.reserve(LF, H, W, 3)
     x = torch.from_numpy(host).cuda()
     out = torch.empty((F, H * SCALE, W * SCALE, 3), dtype=torch.uint8, device=x.device)
+
+    def run_step(src, dst=out, each=None):
+        for k in range(calls):
+            eng.pipeline(src[k * LF:(k + 1) * LF], out=dst[k * LF:(k + 1) * LF])
+            if each:
+                each()
+
     for _ in range(args.warmup):
-        eng.pipeline(x, out=out)
-    elapsed = timed(lambda: eng.pipeline(x, out=out), args.steps)
+        run_step(x)
+    elapsed = timed(lambda: run_step(x), args.steps)
     value = world * F * H * SCALE * W * SCALE * args.steps / elapsed / 1e6
     ms_step = elapsed / args.steps * 1e3
 
@@ -261,10 +275,8 @@ def main():
     # per-stage and per-dominant-kernel device time: HIP events the library records on the launch stream
     eng.set_stage_timing(True)
     per_stage, per_kernel = [], []
-    for _ in range(args.steps):
-        eng.pipeline(x, out=out)
-        per_stage.append(eng.last_stage_ms())
-        per_kernel.append(eng.last_kernel_ms())
+    for _ in range(max(2, args.steps // calls)):
+        run_step(x, each=lambda: (per_stage.append(eng.last_stage_ms()), per_kernel.append(eng.last_kernel_ms())))      # per call of LF frames
     eng.set_stage_timing(False)
     ms_stage = np.mean(np.asarray(per_stage), axis=0)
     ms_kernel = np.mean(np.asarray(per_kernel), axis=0)
@@ -276,17 +288,18 @@ def main():
                 continue
             x2 = torch.from_numpy(make_batch(other, F, H, W, seed=rank)).cuda()
             for _ in range(2):
-                eng.pipeline(x2, out=out)
-            el2 = timed(lambda: eng.pipeline(x2, out=out), max(2, args.steps // 2))
+                run_step(x2)
+            el2 = timed(lambda: run_step(x2), max(2, args.steps // 2))
             others[other] = world * F * H * SCALE * W * SCALE * max(2, args.steps // 2) / el2 / 1e6
             del x2
 
     if rank == 0:
-        sites = F * H * W * 3                                   # LR samples per launch
-        lut_bytes = 3 * 83521 * (1 + SCALE * SCALE)             # every table read once: SURVEY 8(d) LUT_bytes
-        alg = sites * (1 + SCALE * SCALE) + lut_bytes           # 17 B per LR sample + tables
+        sites = LF * H * W * 3                                  # LR samples per launch
+        lut_bytes = 3 * 83521 * (1 + SCALE * SCALE)             # every table read once per launch: SURVEY 8(d) LUT_bytes
+        alg = calls * (sites * (1 + SCALE * SCALE) + lut_bytes)           # 17 B per LR sample + tables
         alg_k2 = sites * (1 + SCALE * SCALE) + 3 * 83521 * SCALE * SCALE
-        workload = "2-stage sdy x4, %d x LR %dx%dx3 -> HR %dx%dx3 per GPU per step, D-%s" % (F, H, W, H * SCALE, W * SCALE, args.dist)
+        workload = "2-stage sdy x4, %d x LR %dx%dx3 -> HR %dx%dx3 per GPU per step%s, D-%s" % (
+            F, H, W, H * SCALE, W * SCALE, "" if calls == 1 else " in %d launches of %d frames" % (calls, LF), args.dist)
         achieved = alg / (ms_step * 1e-3) / 1e9
         k2_ms = float(ms_kernel[-1]) if ms_kernel[-1] > 0 else float(ms_stage[-1])
         counters = load_profile_json("kernel_counters.json", workload if world == 1 else None) if world == 1 else None
@@ -295,7 +308,7 @@ def main():
         issue = load_profile_json("valu_issue.json")
         if counters:
             k2 = counters["final_stage_kernel"]
-            scale_f = F / float(counters.get("frames", F))       # the counters were collected at counters["frames"] frames per launch
+            scale_f = LF / float(counters.get("frames", LF))      # the counters were collected at counters["frames"] frames per launch
             insts = k2["valu_wave_insts_per_launch"] * scale_f
             rate = insts / (k2_ms * 1e-3) / 1e9
             # peak: what the kernel's OWN instruction stream sustains per SIMD with nothing else in the way (tools/ubench/gen_stream_ubench.py:
@@ -321,13 +334,13 @@ def main():
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload, "batch": "rolled copies of two draws (rounds 1-2)" if ROLLED_BATCH else ("every frame its own draw" if F <= MAX_DRAWS else "%d draws, repeated in order to %d frames" % (MAX_DRAWS, F)), "frames_per_gpu": F, "lr": [H, W, 3], "stages": STAGES, "modes": MODES,
+            "config": {"workload": workload, "batch": "rolled copies of two draws (rounds 1-2)" if ROLLED_BATCH else ("every frame its own draw" if F <= MAX_DRAWS else "%d draws, repeated in order to %d frames" % (MAX_DRAWS, F)), "frames_per_gpu": F, "frames_per_launch": LF, "lr": [H, W, 3], "stages": STAGES, "modes": MODES,
                        "scale": SCALE, "luts": "shipped sr_x2sdy fine-tuned int8 tables",
                        "parallelism": "frames sharded over %d GPU(s), no collective" % world,
                        **{"value_D-%s" % k: round(v, 2) for k, v in others.items()}},
             "roofline": {"bound": "hbm", "kernel": "fused 2-stage pipeline: %s | %s" % (eng.kernel_name(False), eng.kernel_name(True)),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic.get("pipeline_bytes_per_step") if traffic else None,
+                         "traffic": traffic.get("pipeline_bytes_per_step") * calls if traffic else None,      # (the JSON holds bytes per launch of every kernel)
                          "algorithmic_bytes_per_step": alg,
                          "stage_ms": [round(float(v), 4) for v in ms_stage],
                          "dominant_kernel": {"name": "stage_tube2_kernel<rgb>" if "tube2" in eng.kernel_name(True) else "stage_tube_kernel<rgb>" if "tube" in eng.kernel_name(True) else eng.kernel_name(True),

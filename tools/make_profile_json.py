@@ -40,7 +40,7 @@ def main(d, tag):
     tube = [k for k in pmc if "stage_tube" in k]
     first = [k for k in pmc if "stage_u1" in k]
     h = _native.source_hash()
-    kc = {"source_hash": h, "workload": workload, "tag": tag, "frames": bench.get("config", {}).get("frames_per_gpu"), "kernels": kernels}
+    kc = {"source_hash": h, "workload": workload, "tag": tag, "frames": bench.get("config", {}).get("frames_per_launch", bench.get("config", {}).get("frames_per_gpu")), "kernels": kernels}
     if tube:
         kc["final_stage_kernel"] = dict(kernels[tube[0]], name=tube[0],
                                         lds_bytes_per_launch=None if kernels[tube[0]]["lds_insts_per_launch"] is None else
