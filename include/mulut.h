@@ -93,10 +93,10 @@ int mulut_stage(mulut_ctx *ctx, int stage, const uint8_t *in, int in_layout, uin
 
 /* The whole cascade for N images: replaces sr/4_test_lut.py:279-306 (= sr/5_test_lut.py:271-307).
  * in: N x (H,W,C) uint8, out: N x (H*scale, W*scale, C) uint8, both in `layout`.
- * Batch size: any N is computed exactly; the fastest path for detailed content (anchor slabs in LDS, x4 final stages) indexes
- * the stage input of one call with 28 bits, so calls whose N*H*W*min(C,3) reaches 2^28 bytes (43 frames of 1080p RGB) route
- * detailed tiles to the gather kernels instead (several times slower on photographs and noise).  Callers with larger batches
- * should make several calls (bench.py: 32 frames per call). */
+ * Batch size: the fastest path for detailed content (anchor slabs in LDS, x4 final stages) indexes the stage input of one
+ * launch with 28 bits; mulut_pipeline therefore runs a batch of N*H*W*min(C,3) >= 2^28 bytes (43 frames of 1080p RGB and up) as
+ * sub-batches that fit -- same result, and the timing helpers report the last sub-batch.  mulut_pipeline_rows and mulut_stage do
+ * not split: a call that large routes its detailed tiles to the gather kernels (several times slower on photographs and noise). */
 int mulut_pipeline(mulut_ctx *ctx, const uint8_t *in, uint8_t *out, int N, int H, int W, int C, int layout,
                    void *stream);
 

@@ -738,7 +738,21 @@ int mulut_pipeline_rows(mulut_ctx *ctx, const uint8_t *in, int in_row0, int in_r
 
 int mulut_pipeline(mulut_ctx *ctx, const uint8_t *in, uint8_t *out, int N, int H, int W, int C, int layout,
                    void *stream) {
-    return mulut_pipeline_rows(ctx, in, 0, H, out, 0, H, N, H, W, C, layout, stream);
+    if (!ctx || !in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MULUT_EINVAL;
+    if (!ctx->configured) return MULUT_ENOTCONFIGURED;
+    // The work lists of the detailed-tile path index one launch's stage input with 28 bits (DetailArgs::desc): a batch beyond that
+    // would send its detailed tiles to the gather kernels.  Images are independent, so a large batch runs as sub-batches that fit
+    // (the timing helpers then report the last sub-batch).
+    const long long per_image = (long long)H * W * imin(C, 3);
+    const long long fit = ((1ll << 28) - 1) / per_image;
+    if (fit < 1 || N <= fit) return mulut_pipeline_rows(ctx, in, 0, H, out, 0, H, N, H, W, C, layout, stream);
+    const long long in_image = (long long)H * W * C, out_image = in_image * ctx->scale * ctx->scale;
+    for (long long n0 = 0; n0 < N; n0 += fit) {
+        const int n = (int)(N - n0 < fit ? N - n0 : fit);
+        const int rc = mulut_pipeline_rows(ctx, in + n0 * in_image, 0, H, out + n0 * out_image, 0, H, n, H, W, C, layout, stream);
+        if (rc) return rc;
+    }
+    return MULUT_OK;
 }
 
 int mulut_set_stage_timing(mulut_ctx *ctx, int enable) {

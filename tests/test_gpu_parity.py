@@ -555,3 +555,21 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
     sg = rec["config"]["strips_gather"]
     assert sg["ranks_in_group"] == 2 and sg["single_root"]["value"] > 0 and sg["rotate"]["value"] > 0
     assert sg["rotate"]["max_bytes_into_one_rank_per_step"] * 2 == sg["single_root"]["max_bytes_into_one_rank_per_step"]
+
+
+@pytest.mark.gpu
+def test_large_batch_runs_as_sub_batches(eng, shipped_luts):
+    """A batch whose stage input passes 2^28 bytes is split by mulut_pipeline (the detailed-tile work lists index 28 bits):
+    same bytes as frame-by-frame calls, on detailed content, and no slower path (the anchor-slab kernels still run)."""
+    from mulut_amd.synth import noise_frames
+    h, w = 1080, 1920
+    n = (1 << 28) // (h * w * 3) + 2          # 45 frames: one more sub-batch than fits
+    base = dev(noise_frames(3, h, w, 3, 7))
+    x = base.repeat((n + 2) // 3, 1, 1, 1)[:n].contiguous()
+    out = torch.empty((n, 4 * h, 4 * w, 3), dtype=torch.uint8, device="cuda")
+    eng.pipeline(x, out=out)
+    ref = eng.pipeline(base)
+    for k in range(n):
+        assert torch.equal(out[k], ref[k % 3]), k
+    d = eng.last_detail_counters()
+    assert sum(d["samples_per_anchor"]) > 0          # the last sub-batch went through the anchor slabs
