@@ -93,10 +93,11 @@ int mulut_stage(mulut_ctx *ctx, int stage, const uint8_t *in, int in_layout, uin
 
 /* The whole cascade for N images: replaces sr/4_test_lut.py:279-306 (= sr/5_test_lut.py:271-307).
  * in: N x (H,W,C) uint8, out: N x (H*scale, W*scale, C) uint8, both in `layout`.
- * Batch size: the fastest path for detailed content (anchor slabs in LDS, x4 final stages) indexes the stage input of one
- * launch with 28 bits; mulut_pipeline therefore runs a batch of N*H*W*min(C,3) >= 2^28 bytes (43 frames of 1080p RGB and up) as
- * sub-batches that fit -- same result, and the timing helpers report the last sub-batch.  mulut_pipeline_rows and mulut_stage do
- * not split: a call that large routes its detailed tiles to the gather kernels (several times slower on photographs and noise). */
+ * Batch size: the device work lists index one launch with fixed widths (28 bits of byte offset into the stage input on the
+ * detailed-tile path of x4 final stages, 30-bit pixel ids, 32-bit site ids).  Every entry point -- this one, mulut_pipeline_rows,
+ * mulut_stage -- runs a STAGE whose launch would exceed a width as sub-launches of whole images that fit (43 frames of 1080p RGB
+ * per final-stage launch): same result, same kernels; no batch size falls to a slower path.  (The timing helpers then report the
+ * last sub-launch of a stage.)  A single image beyond 2^28 bytes takes the gather kernels for its detailed tiles. */
 int mulut_pipeline(mulut_ctx *ctx, const uint8_t *in, uint8_t *out, int N, int H, int W, int C, int layout,
                    void *stream);
 
@@ -112,8 +113,9 @@ int mulut_pipeline_rows(mulut_ctx *ctx, const uint8_t *in, int in_row0, int in_r
  * reach of the d / y patterns over the four rotations). */
 int mulut_halo(const mulut_ctx *ctx);
 
-/* Pre-size the intermediate-stage workspace so that later pipeline calls allocate nothing
- * (required before capturing a pipeline call into a hipGraph). */
+/* Pre-size the intermediate-stage workspace and every device work list so that later pipeline calls of at most this shape
+ * allocate nothing (required before capturing a pipeline call into a hipGraph).  Buffers that only a stage's sub-launches
+ * use (see mulut_pipeline, "Batch size") are sized for the largest sub-launch. */
 int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C);
 
 /* Per-stage device timing for bench.py's roofline leg: when enabled, every mulut_pipeline[_rows]
@@ -182,6 +184,8 @@ int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int
  *   window kernel, flagged sites are recomputed through a device work list), 2 = window kernel (full table in LDS) on every
  *   tile, 3 = tube kernel on every tile.  (1: the first one-read-per-neighbour kernel, retired: MULUT_EINVAL.)
  * "first_stage_detail_per_1024": tile threshold of first_stage_kernel 0 (default 24).
+ * "u1t_persist" (experiments): 0 (default) = one workgroup per tile of the 1-byte-row tube kernel, 1..8 = that many persistent
+ *   workgroups per CU walking XCD-contiguous tile ranges.  Per context, like every other key.
  * Unknown key or value: MULUT_EINVAL.
  * hipGraph capture: call mulut_reserve() for the largest (N, H, W, C) first -- the context's workspace, verdict and work-list
  * buffers are then never reallocated by smaller calls; a LARGER later call reallocates them and invalidates graphs captured

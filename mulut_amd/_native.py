@@ -48,8 +48,62 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(_CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def audit_tube2_isa(asm_path=None):
+    """stage_tube2_kernel keeps the rows of the pass in flight in v88..v127 ACROSS asm statements (tools/gen_tube2_asm.py); the only
+    things that keep the compiler out of them are its register budget (amdgpu_waves_per_eu) and the clobber lists, and neither binds a
+    short-lived temporary by contract.  So the library is not accepted on trust: this compiles mulut_kernels.hip to gfx950 assembly
+    (or reads `asm_path`) and raises unless, in every stage_tube2_kernel instance, (i) no instruction outside the inline-asm blocks
+    names v<TUBE2_ROW0> or above, (ii) no AGPR is used and (iii) at most 128 VGPRs are allocated (the kernel is launched with 1024
+    threads at 4 waves per SIMD: 512 / 4 registers per lane).  Returns the number of kernels audited."""
+    import re
+    import tempfile
+    hipcc = _hipcc()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot audit stage_tube2_kernel")
+    inc = open(os.path.join(_CSRC, "mulut_tube2_asm.inc")).read()
+    row0 = int(re.search(r"#define TUBE2_ROW0 (\d+)", inc).group(1))
+    with tempfile.TemporaryDirectory() as td:
+        if asm_path is None:
+            asm_path = os.path.join(td, "mulut_kernels.s")
+            flags = [f for f in HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+            subprocess.check_call([hipcc] + flags + ["--cuda-device-only", "-S", "-o", asm_path, os.path.join(_CSRC, "mulut_kernels.hip")],
+                                  stderr=subprocess.DEVNULL)
+        lines = open(asm_path).read().splitlines()
+    reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+    kernels, name, in_asm, bad = [], None, False, []
+    for line in lines:
+        m = re.match(r"^(_ZN5mulut18stage_tube2_kernel\w+):", line)
+        if m:
+            name, in_asm = m.group(1), False
+            kernels.append(name)
+            continue
+        m = re.match(r"^\s*\.set (_ZN5mulut18stage_tube2_kernel\w+)\.(num_vgpr|num_agpr), (\d+)", line)
+        if m:
+            if (m.group(2) == "num_agpr" and int(m.group(3)) != 0) or (m.group(2) == "num_vgpr" and int(m.group(3)) > 128):
+                bad.append((m.group(1), line.strip()))
+            continue
+        if name is None:
+            continue
+        if "s_endpgm" in line:
+            name = None
+        elif "#ASMSTART" in line:
+            in_asm = True
+        elif "#ASMEND" in line:
+            in_asm = False
+        elif not in_asm and not line.lstrip().startswith((";", ".")):
+            for a, lo, hi in reg.findall(line.split(";")[0]):
+                if (int(a) if a else int(hi)) >= row0:
+                    bad.append((name, line.strip()))
+    if len(kernels) != 3:          # generic, planar, rgb
+        raise RuntimeError("tube2 audit: expected 3 stage_tube2_kernel instances, found %d" % len(kernels))
+    if bad:
+        raise RuntimeError("tube2 audit failed (the compiler touched the kernel's private registers, or the register budget changed): %r" % (bad[:5],))
+    return len(kernels)
+
+
 def build(force=False, verbose=False):
-    """Compile the HIP extension in-tree for gfx950 (cross-compiles without a GPU)."""
+    """Compile the HIP extension in-tree for gfx950 (cross-compiles without a GPU).  The library is only put in place after
+    audit_tube2_isa() has accepted the assembly of the same sources with the same flags."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = _hipcc()
@@ -62,6 +116,7 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     try:
         subprocess.check_call(cmd, cwd=_CSRC)
+        audit_tube2_isa()
         os.replace(tmp, LIB_PATH)
     finally:
         if os.path.exists(tmp):

@@ -57,6 +57,7 @@ struct mulut_ctx {
     int stat_from_k1 = 1;          // tuning "stat_from_first_stage": the final stage's statistic looks only at tiles the first stage marked
     int fix_variant = 0;           // tuning "fix_kernel"
     int tube2 = 1;                 // tuning "tube_pipelined": 1 = stage_tube2_kernel (hand-scheduled LDS reads) where the mode list has one, 0 = stage_tube_kernel
+    int u1t_persist = 0;           // tuning "u1t_persist": persistent workgroups per CU of the 1-byte-row tube kernel (0 = one workgroup per tile)
     int detail_kernel = 0;         // tuning "detail_kernel": 0 = anchor slabs in LDS (when the launch qualifies), 1 = full-table gather kernel
     int first_kernel = 0;   // 1-byte-row stages: 0 auto (tube kernel, detailed tiles to the window kernel), 2 window kernel (full table in
                             // LDS) on every tile, 3 tube kernel on every tile
@@ -389,8 +390,10 @@ static hipError_t tube_launch(mulut_ctx *ctx, const StageArgs &a, const BandArgs
 // Launch one stage: input view holds LR rows [in.row0, ...), outputs for LR rows [oy0, oy1).
 // C channels are processed (<= 3); they may be a group of an image with more (then the views carry that image's strides and
 // packed_ok is false: the packed-RGB store needs a pixel stride of exactly 3)
-static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
-                     int C, int oy0, int oy1, hipStream_t st, bool packed_ok = true) {
+// k1_ref / k1_n0: when this launch is a sub-launch of a larger one (run_stage below), the buffer and first image of the WHOLE launch --
+// what the first stage's tile marks are recorded against
+static int run_stage_one(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
+                         int C, int oy0, int oy1, hipStream_t st, bool packed_ok, const uint8_t *k1_ref, int k1_n0) {
     StageArgs a;
     memset(&a, 0, sizeof(a));
     int rc = stage_tables(ctx, stage, a.lut);
@@ -426,8 +429,8 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     a.tiles_y = (oy1 - oy0 + th - 1) / th;
     if (u == 1 && last) a.use_fma = 0;     // (a final stage with 1-byte rows -- scale 1 -- takes the integer epilogue)
     // marks of the first-stage launch that produced this stage's input (same buffer, same shape); consumed here, never kept
-    const bool k1_marks = ctx->k1_valid && ctx->k1_out == in.p && ctx->k1_N == N && ctx->k1_W == W && ctx->k1_H == H && ctx->k1_oy0 <= oy0 &&
-                          oy1 <= ctx->k1_oy1;      // the marks cover exactly the rows that launch wrote: never index past its tile grid
+    const bool k1_marks = ctx->k1_valid && ctx->k1_out == k1_ref && k1_n0 + N <= ctx->k1_N && ctx->k1_W == W && ctx->k1_H == H && ctx->k1_oy0 <= oy0 &&
+                          oy1 <= ctx->k1_oy1;      // the marks cover exactly the images and rows that launch wrote: never index past its tile grid
     ctx->k1_valid = false;
     if (u == 1) {
         // (any mode list: the bands live in LDS per PATTERN, a repeated pattern is simply computed again into the int32 sum)
@@ -453,7 +456,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         a.tile_count = ctx->tlist;
         a.tile_list = ctx->tlist + 16;
         a.verdict_take = route ? 0 : -1;
-        MAIN_KERNEL(ctx, stage, st, launch_stage_u1t(a, b1, (unsigned)ctx->u1_detail_per_1024, ctx->num_cus, st));
+        MAIN_KERNEL(ctx, stage, st, launch_stage_u1t(a, b1, (unsigned)ctx->u1_detail_per_1024, ctx->num_cus, ctx->u1t_persist, st));
         if (route) HIP_TRY(ctx, launch_stage_u1w_list(a, ctx->num_cus, st));
         HIP_TRY(ctx, launch_stage_u1_fix(a, ctx->num_cus, st));
         ctx->k1_valid = route;
@@ -478,7 +481,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         stage_u1t_tile(t2w, t2h);
         a.tiles_x = (W + t2w - 1) / t2w;
         a.tiles_y = (oy1 - oy0 + t2h - 1) / t2h;
-        MAIN_KERNEL(ctx, stage, st, launch_stage_u2t(a, b2, ctx->num_cus, st));
+        MAIN_KERNEL(ctx, stage, st, launch_stage_u2t(a, b2, ctx->num_cus, ctx->u1t_persist, st));
         return MULUT_OK;
     }
     if (!tube) {
@@ -513,7 +516,7 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
     }
     if (ctx->stat_from_k1 && k1_marks) {
         a.k1_hdr = ctx->tlist;
-        a.k1_tiles_x = ctx->k1_tiles_x; a.k1_tiles_y = ctx->k1_tiles_y; a.k1_oy0 = ctx->k1_oy0;
+        a.k1_tiles_x = ctx->k1_tiles_x; a.k1_tiles_y = ctx->k1_tiles_y; a.k1_oy0 = ctx->k1_oy0; a.k1_n0 = k1_n0;
     }
     HIP_TRY(ctx, launch_tile_stat(a, ctx->verdict, (uint32_t)ctx->hybrid_oob_per_1024, st, slab ? ctx->det_thist : nullptr, slab ? ctx->det_ctl + kDetAny : nullptr));
     a.k1_hdr = nullptr;
@@ -539,6 +542,46 @@ static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out,
         HIP_TRY(ctx, launch_stage_up(g, u, mode, st));
     }
     HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st, ctx->fix_variant));
+    return MULUT_OK;
+}
+
+// Index widths of the device work lists, per launch: site ids of the 1-byte-row / u == 2 tube kernels 32 bits (N C H W), pixel ids of the
+// u == 4 fix-up list 30 bits (N H W), sample descriptors of the detailed-tile path 28 bits of byte offset into the stage input.  Images
+// are independent (sr/4_test_lut.py:257-259 fans them out one by one), so a launch beyond a width runs as sub-launches of whole images
+// that fit -- every entry point (mulut_stage, mulut_pipeline_rows, mulut_pipeline) comes through here, none falls to a slower kernel
+// because of its batch size.  How many images of the launch fit one sub-launch (>= 1; N when nothing binds):
+static int stage_fit_images(const mulut_ctx *ctx, int stage, const View &in, int N, int H, int W, int C) {
+    const int u = stage_u(ctx, stage);
+    unsigned long long fit = (unsigned long long)N;
+    auto cap = [&](unsigned long long limit, unsigned long long per_image) {
+        const unsigned long long f = per_image ? (limit - 1) / per_image : fit;
+        if (f < fit) fit = f;
+    };
+    if (u == 1 || u == 2) cap(1ull << 32, (unsigned long long)C * H * W);
+    if (u == 4 && ctx->final_kernel != 1) {
+        cap(1ull << 30, (unsigned long long)H * W);
+        if (ctx->final_kernel != 5 && ctx->detail_kernel == 0 && ctx->n_modes <= 3 && in.sX == 1)      // (what detail_slab_supported() asks of a launch)
+            cap(1ull << 28, (unsigned long long)(in.sN < 0 ? -in.sN : in.sN));
+    }
+    return fit < 1 ? 1 : (int)fit;
+}
+
+static int run_stage(mulut_ctx *ctx, int stage, const View &in, const View &out, int out_layout, int N, int H, int W,
+                     int C, int oy0, int oy1, hipStream_t st, bool packed_ok = true) {
+    const int fit = stage_fit_images(ctx, stage, in, N, H, W, C);
+    if (N <= fit) return run_stage_one(ctx, stage, in, out, out_layout, N, H, W, C, oy0, oy1, st, packed_ok, in.p, 0);
+    // the first stage's tile marks (if this stage reads what it wrote) serve every sub-launch: kept across the calls that consume them
+    const bool k1_valid = ctx->k1_valid;
+    for (int n0 = 0; n0 < N; n0 += fit) {
+        View vin = in, vout = out;
+        vin.p += (long long)n0 * in.sN;
+        vout.p += (long long)n0 * out.sN;
+        ctx->k1_valid = k1_valid;
+        const int rc = run_stage_one(ctx, stage, vin, vout, out_layout, imin(fit, N - n0), H, W, C, oy0, oy1, st, packed_ok, in.p, n0);
+        if (rc) return rc;
+    }
+    // a split first stage leaves the marks of its last sub-launch only: the next stage must look at every tile itself
+    ctx->k1_valid = false;
     return MULUT_OK;
 }
 
@@ -644,9 +687,12 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
                 stage_band_tile(tw, th);
                 StageArgs t;
                 memset(&t, 0, sizeof(t));
-                t.N = N; t.tiles_x = (W + tw - 1) / tw; t.tiles_y = (H + th - 1) / th;
-                t.in.sN = (long long)H * W * C;
-                t.in.sX = 1; t.C = C; t.M = ctx->n_modes; t.H = H; t.W = W;
+                // the final stage of a batch beyond the 28-bit sample descriptors runs as sub-launches (run_stage): the detailed-tile path's
+                // buffers are sized for the largest of those, so that a captured call never allocates
+                t.in.sN = (long long)H * W * imin(C, 3);       // (a cascade's final stage reads the planar workspace: groups of <= 3 channels)
+                t.in.sX = 1; t.C = imin(C, 3); t.M = ctx->n_modes; t.H = H; t.W = W;
+                t.N = imin(N, stage_fit_images(ctx, ctx->stages, t.in, N, H, W, t.C));
+                t.tiles_x = (W + tw - 1) / tw; t.tiles_y = (H + th - 1) / th;
                 if (detail_slab_supported(t)) {       // launches of this size that the anchor-slab path would take
                     rc = ensure_detail(ctx, (size_t)t.N * t.tiles_x * t.tiles_y, detail_items_max(t), detail_ids_count(t), detail_blocks_count(t));
                     if (rc) return rc;
@@ -740,19 +786,8 @@ int mulut_pipeline(mulut_ctx *ctx, const uint8_t *in, uint8_t *out, int N, int H
                    void *stream) {
     if (!ctx || !in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MULUT_EINVAL;
     if (!ctx->configured) return MULUT_ENOTCONFIGURED;
-    // The work lists of the detailed-tile path index one launch's stage input with 28 bits (DetailArgs::desc): a batch beyond that
-    // would send its detailed tiles to the gather kernels.  Images are independent, so a large batch runs as sub-batches that fit
-    // (the timing helpers then report the last sub-batch).
-    const long long per_image = (long long)H * W * imin(C, 3);
-    const long long fit = ((1ll << 28) - 1) / per_image;
-    if (fit < 1 || N <= fit) return mulut_pipeline_rows(ctx, in, 0, H, out, 0, H, N, H, W, C, layout, stream);
-    const long long in_image = (long long)H * W * C, out_image = in_image * ctx->scale * ctx->scale;
-    for (long long n0 = 0; n0 < N; n0 += fit) {
-        const int n = (int)(N - n0 < fit ? N - n0 : fit);
-        const int rc = mulut_pipeline_rows(ctx, in + n0 * in_image, 0, H, out + n0 * out_image, 0, H, n, H, W, C, layout, stream);
-        if (rc) return rc;
-    }
-    return MULUT_OK;
+    // (batches beyond the index widths of the device work lists run as sub-launches per stage: run_stage)
+    return mulut_pipeline_rows(ctx, in, 0, H, out, 0, H, N, H, W, C, layout, stream);
 }
 
 int mulut_set_stage_timing(mulut_ctx *ctx, int enable) {
@@ -854,7 +889,7 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
     }
     if (!strcmp(key, "u1t_persist")) {      // experiment: persistent workgroups per CU of the 1-byte-row tube kernel (0 = one per tile)
         if (value < 0 || value > 8) return MULUT_EINVAL;
-        g_u1t_persist = value;
+        ctx->u1t_persist = value;
         return MULUT_OK;
     }
     if (!strcmp(key, "first_stage_detail_per_1024")) {

@@ -608,6 +608,9 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                 }
             }
             // sites that may have left the tube: onto the fix-up list, one atomic per wave and pixel slot (rare)
+#if defined(MULUT_VARIANT_nofixlist)    /* timing-only: nothing is listed (flagged sites stay wrong) */
+            if (dirty == 0xFFFFFFFFu) a.fix_list[0] = 0u;
+#else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool d = ((dirty >> i) & 1u) != 0u && x + i < a.W;
@@ -620,6 +623,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                     if (d) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)(((n * a.C + c) * a.H + y) * a.W + x + i);
                 }
             }
+#endif
         }
         }
         K1_STAMP(3);          // the sites
@@ -671,10 +675,9 @@ __global__ void __launch_bounds__(256) stage_u1_fix_kernel(StageArgs a) {
 }
 
 void stage_u1t_tile(int &tw, int &th) { tw = K1T_TW; th = K1T_TH; }
-int g_u1t_persist = 0;      // experiment knob (mulut_set_tuning "u1t_persist")
 
 template <int U>
-static hipError_t launch_u1t_t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st) {
+static hipError_t launch_u1t_t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st) {
     {
         const hipError_t e = raise_lds_limit((const void *)stage_u1t_kernel<U>, 80 * 1024);
         if (e != hipSuccess) return e;
@@ -682,16 +685,16 @@ static hipError_t launch_u1t_t(const StageArgs &a, const BandArgs &b, unsigned d
     const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
     // persist_per_cu > 0: that many persistent workgroups per CU walk XCD-contiguous tile ranges; 0: one workgroup per tile
-    const long long want = g_u1t_persist > 0 ? (long long)g_u1t_persist * num_cus : ntiles;     // (three 512-thread workgroups fit a CU)
+    const long long want = persist_per_cu > 0 ? (long long)persist_per_cu * num_cus : ntiles;     // (three 512-thread workgroups fit a CU)
     const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
     const size_t lds = 3 * (size_t)u1t_band_bytes<U>() + kU1tTileBytes + 16;
     hipLaunchKernelGGL(stage_u1t_kernel<U>, dim3(grid), dim3(K1T_NT), lds, st, a, b, (uint32_t)detail_per_1024);
     return hipGetLastError();
 }
 
-hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st) {
+hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st) {
     if (a.C > 3 || a.M > kMaxModes || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
-    return launch_u1t_t<1>(a, b, detail_per_1024, num_cus, st);
+    return launch_u1t_t<1>(a, b, detail_per_1024, num_cus, persist_per_cu, st);
 }
 
 hipError_t launch_stage_u1w_list(const StageArgs &a, int num_cus, hipStream_t st) {
@@ -752,9 +755,9 @@ __global__ void __launch_bounds__(256) stage_up_fix_site_kernel(StageArgs a) {
 
 // the same kernel family on a FINAL stage with u == 2 (4-value rows, 2 x 2 output blocks): b.band[m] = 8-byte-per-slot
 // tube band; no tile routing; flagged sites go to stage_up_fix_site_kernel through a.fix_list
-hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st) {
+hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, int num_cus, int persist_per_cu, hipStream_t st) {
     if (a.C > 3 || a.M > 4 || !a.fix_list || !a.fix_count || a.verdict_take >= 0) return hipErrorInvalidValue;
-    hipError_t e = launch_u1t_t<2>(a, b, 0u, num_cus, st);
+    hipError_t e = launch_u1t_t<2>(a, b, 0u, num_cus, persist_per_cu, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(stage_up_fix_site_kernel<2>, dim3((unsigned)(4 * num_cus)), dim3(256), 0, st, a);
     return hipGetLastError();

@@ -53,6 +53,7 @@ struct StageArgs {
     // without looking at them
     const uint32_t *k1_hdr;
     int k1_tiles_x, k1_tiles_y, k1_oy0;
+    int k1_n0;              // image 0 of this launch is image k1_n0 of that first-stage launch (sub-launches of a large batch)
     // tube kernel: pixels with a pass outside the tube are appended here (id = (n H + y) W + x) and recomputed by
     // stage_up_fix_kernel; *fix_count is zeroed by the host side before the stage
     uint32_t *fix_list;
@@ -112,15 +113,14 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant);
 // the same stage on the tube band (b.band[m] = dword-per-slot band of mode m, kTube1BandBytes): computes every tile
 // whose local-detail statistic is at most detail_per_1024 (all tiles when a.tile_list is null), lists the others in
 // a.tile_list and the sites that may have left the tube in a.fix_list
-hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, hipStream_t st);
+hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st);
 // final stage with u == 2 on the tube band (8 bytes per slot: four 16-bit fields), + its site fix-up
-hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, int num_cus, hipStream_t st);
+hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, int num_cus, int persist_per_cu, hipStream_t st);
 // full-table kernel over the tiles marked in a.tile_list[]
 hipError_t launch_stage_u1w_list(const StageArgs &a, int num_cus, hipStream_t st);
 // recompute the sites in a.fix_list[0 .. *a.fix_count) from the full tables (1-byte rows)
 hipError_t launch_stage_u1_fix(const StageArgs &a, int num_cus, hipStream_t st);
 void stage_u1t_tile(int &tw, int &th);
-extern int g_u1t_persist;
 // final stage with u in {2,3,4}: u*u bytes out per site
 hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t st);
 // u == 4 and more than four modes (per-rotation accumulators)

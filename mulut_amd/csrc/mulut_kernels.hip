@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) tile_stat_kernel(StageArgs a, uint32_t *v
     if (a.k1_hdr && a.k1_hdr[2] != 0u) {
         // the statistic folded into the first stage: its tube kernel routed its 64x64 tiles by the detail of ITS input, and what it
         // left unmarked is smooth enough here too (a wrong guess costs fix-up work, never exactness)
-        const int k1 = (n * a.k1_tiles_y + (y0 - a.k1_oy0) / 64) * a.k1_tiles_x + x0 / 64;
+        const int k1 = ((n + a.k1_n0) * a.k1_tiles_y + (y0 - a.k1_oy0) / 64) * a.k1_tiles_x + x0 / 64;
         if (a.k1_hdr[16 + k1] == 0u) {          // workgroup-uniform
             if (threadIdx.x == 0) verdict[id] = 0u;
             return;
@@ -1218,6 +1218,9 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                 store_rgb<4>(a, n, y, x, oR, oG, o);
             }
             // dirty samples (pixel, channel) go on the fix-up list: one atomic per wave and channel (rare), compacted by lane rank
+#if defined(MULUT_VARIANT_nofixlist)    /* timing-only: nothing is listed (flagged samples stay wrong) */
+            if (dmask == 0xFFFFFFFFu) a.fix_list[0] = 0u;
+#else
             if (__ballot(dmask != 0u) != 0ull) {
                 const uint32_t pixel_id = (uint32_t)((n * a.H + y) * a.W + x);
                 for (int c = 0; c < a.C; ++c) {
@@ -1231,6 +1234,7 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                     if (d) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = pixel_id | ((uint32_t)c << 30);
                 }
             }
+#endif
         }
         T2_STAMP(3);       // output stores, fix-up list
         stash(nxt_item, pix);      // the wave's image is its own: every read of the current tile has returned (the pipeline drained)

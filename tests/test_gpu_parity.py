@@ -573,3 +573,35 @@ def test_large_batch_runs_as_sub_batches(eng, shipped_luts):
         assert torch.equal(out[k], ref[k % 3]), k
     d = eng.last_detail_counters()
     assert sum(d["samples_per_anchor"]) > 0          # the last sub-batch went through the anchor slabs
+
+
+@pytest.mark.gpu
+def test_large_strip_and_stage_calls_run_as_sub_launches(eng, shipped_luts):
+    """mulut_pipeline_rows (the multi-GPU entry point) and mulut_stage with more than 2^28 bytes of stage input: the final stage
+    runs as sub-launches of whole images inside the library, so the detailed tiles still take the anchor-slab kernels (no batch size
+    falls to the gather kernels) and every image equals its frame-by-frame result."""
+    from mulut_amd.synth import noise_frames
+    h, w, y1 = 1080, 1920, 544
+    rows = y1 + eng.halo                                       # the strip [0, y1) and its halo below
+    n = (1 << 28) // (rows * w * 3) + 2                        # more strips than one final-stage launch indexes
+    base = dev(noise_frames(3, h, w, 3, 11))
+    band = base[:, :rows].repeat((n + 2) // 3, 1, 1, 1)[:n].contiguous()
+    assert band.numel() > (1 << 28)
+    out = eng.pipeline_rows(band, 0, 0, y1, h)
+    d = eng.last_detail_counters()
+    assert sum(d["samples_per_anchor"]) > 0.9 * 3 * y1 * w     # the last sub-launch: (nearly) every sample through the anchor slabs
+    ref = eng.pipeline_rows(base[:, :rows].contiguous(), 0, 0, y1, h)
+    for k in range(n):
+        assert torch.equal(out[k], ref[k % 3]), k
+    del out, band
+    # the final stage alone on a planar batch of the same size
+    mid = eng.stage(1, base, out_layout=0)                     # [3][C][H][W]
+    n2 = (1 << 28) // (h * w * 3) + 2
+    big = mid.repeat((n2 + 2) // 3, 1, 1, 1)[:n2].contiguous()
+    got = eng.stage(2, big, layout=0, out_layout=1)
+    d = eng.last_detail_counters()
+    assert sum(d["samples_per_anchor"]) > 0.9 * 3 * h * w
+    want = eng.stage(2, mid, layout=0, out_layout=1)
+    for k in range(n2):
+        assert torch.equal(got[k], want[k % 3]), k
+    assert torch.equal(want, eng.pipeline(base))

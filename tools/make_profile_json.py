@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from mulut_amd import _native  # noqa: E402
 
 
-def main(d, tag):
+def main(d, tag, suffix=""):
     pmc = json.load(open(os.path.join(d, "pmc_summary.json")))
     bench = json.loads(open(os.path.join(d, "bench_under_stats.json")).read() or "{}")
     workload = bench.get("config", {}).get("workload", "")
@@ -45,15 +45,15 @@ def main(d, tag):
         kc["final_stage_kernel"] = dict(kernels[tube[0]], name=tube[0],
                                         lds_bytes_per_launch=None if kernels[tube[0]]["lds_insts_per_launch"] is None else
                                         kernels[tube[0]]["lds_insts_per_launch"] * 64 * 16 * 10.0 / 13.4)   # ~10 of 13.4 LDS instructions per pass are 16-byte row reads
-    json.dump(kc, open(os.path.join(ROOT, "profiles", "kernel_counters.json"), "w"), indent=1)
+    json.dump(kc, open(os.path.join(ROOT, "profiles", "kernel_counters%s.json" % suffix), "w"), indent=1)
     tr = {"source_hash": h, "workload": workload, "tag": tag, "kernels": traffic,
           "final_stage_bytes_per_launch": sum(traffic[k].get("hbm_bytes", 0) for k in final),
           "pipeline_bytes_per_step": sum(traffic[k].get("hbm_bytes", 0) for k in final + first)}
-    json.dump(tr, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+    json.dump(tr, open(os.path.join(ROOT, "profiles", "hbm_traffic%s.json" % suffix), "w"), indent=1)
     print(json.dumps({"source_hash": h, "final_stage_bytes_per_launch": tr["final_stage_bytes_per_launch"],
                       "pipeline_bytes_per_step": tr["pipeline_bytes_per_step"],
                       "tube_valu_insts": kc.get("final_stage_kernel", {}).get("valu_wave_insts_per_launch")}))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "round")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "round", sys.argv[3] if len(sys.argv) > 3 else "")

@@ -9,7 +9,9 @@ OUT=$R/gpurun_out/prof_$TAG; mkdir -p "$OUT"
 ( cd "$R" && python -c 'from mulut_amd import _native; _native.build()' ) || exit 1
 export MULUT_NO_BUILD=1          # a profiled process has the GPU initialised and must not start hipcc
 cd /tmp && export TMPDIR=/tmp
-ARGS="--cpu-crop 0 --steps 4 --warmup 2 --skip-other --skip-strips"
+# DIST=real|noise profiles that input distribution; the JSONs then carry the suffix (profiles/kernel_counters_real.json ...)
+DIST=${DIST:-natural}
+ARGS="--cpu-crop 0 --steps 4 --warmup 2 --skip-other --skip-strips --dist $DIST"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$R/bench.py" $ARGS > "$OUT/stats.log" 2>&1 || tail -3 "$OUT/stats.log"
 find "$OUT/stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 grep '^{' "$OUT/stats.log" | tail -1 > "$OUT/bench_under_stats.json"
@@ -22,4 +24,4 @@ for k in sq lds rd wr; do
   timeout -k 10 300 rocprofv3 --pmc ${P[$k]} --output-format csv -d "$OUT/$k" -- python "$R/bench.py" $ARGS > "$OUT/$k.log" 2>&1 || { echo "pass $k failed"; tail -3 "$OUT/$k.log"; }
 done
 python "$R/tools/summarize_pmc.py" "$OUT" > "$OUT/pmc_summary.json"
-python "$R/tools/make_profile_json.py" "$OUT" "$TAG"
+if [ "$DIST" = natural ]; then python "$R/tools/make_profile_json.py" "$OUT" "$TAG"; else python "$R/tools/make_profile_json.py" "$OUT" "$TAG" "_$DIST"; fi
