@@ -222,6 +222,8 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant) {
 constexpr int K1T_TW = 64, K1T_TH = 64, K1T_NT = 512;      // 512 threads take the tile's 64 x 64 sites in two halves of 32 rows
 constexpr int K1T_PW = K1T_TW + 2 * kHalo, K1T_PH = K1T_TH + 2 * kHalo;
 constexpr int kU1tTileBytes = 3 * K1T_PH * K1T_PW * 2;
+constexpr int kU1tDirtyBytes = 3 * K1T_TH * (K1T_TW / 4);          // one byte per four-pixel group of the tile
+static_assert(kU1tDirtyBytes == 6 * K1T_NT, "the list pass gives every thread six group bytes");
 
 // accumulators of one site: u == 1 one int32; u == 2 two rotation-pair sets of four 16-bit fields (value + 128 rows, as
 // the u == 4 kernels: a02 holds rotations 0 and 2 -- the latter added in reversed element order -- a13 rotations 1 and 3)
@@ -388,6 +390,8 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_tile = smem + 3 * BB;
     uint32_t *s_cnt = (uint32_t *)(smem + 3 * BB + kU1tTileBytes);     // [0] detailed groups, [1] groups looked at
+    uint8_t *s_dirty = smem + 3 * BB + kU1tTileBytes + 16;              // [channel][tile row][16 four-pixel groups]: dirty bit per pixel of the group
+    uint32_t *s_scan = (uint32_t *)(s_dirty + kU1tDirtyBytes);          // [0..7] flagged sites per wave, [8] where the tile's entries start in the fix-up list
     if (lds_addr_of(smem) != 0u) __builtin_trap();      // the band reads assume the dynamic LDS block starts at address 0 (no static LDS here): fail loudly, never skip the work
 
     for (int m = 0; m < a.M; ++m) {
@@ -432,6 +436,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
             asm volatile("" : "+v"(z));      // made here: the compiler otherwise keeps a zero pair live across the whole kernel -- in scratch
             s_cnt[0] = z; s_cnt[1] = z;
         }
+        for (int i = opaque_tid(); i < kU1tDirtyBytes / 4; i += NT) ((uint32_t *)s_dirty)[i] = 0u;      // (read again only after the tile's barriers)
         constexpr int GR = (TW + 8) / 4;            // 18 four-pixel groups cover image columns x0-4 .. x0+67
         // a group of four pixels of one image row, as two packed byte pairs per channel (edge columns replicated)
         auto group_hwc = [&](int row, int g, uint32_t (&bp)[6]) {
@@ -607,25 +612,56 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                         if (x + i < a.W) dst[i * a.out.sX] = (uint8_t)(packed >> (8 * i));
                 }
             }
-            // sites that may have left the tube: onto the fix-up list, one atomic per wave and pixel slot (rare)
-#if defined(MULUT_VARIANT_nofixlist)    /* timing-only: nothing is listed (flagged sites stay wrong) */
-            if (dirty == 0xFFFFFFFFu) a.fix_list[0] = 0u;
-#else
+            // sites that may have left the tube: noted per four-pixel group in LDS; the workgroup appends them to the fix-up list after the
+            // tile with ONE memory-side atomic.  (One atomic per wave and pixel slot, as rounds 2-3 had it, is 60 k atomics on one
+            // address for 8 x 270x480 frames of a steep field: they took 0.4 of the kernel's 0.48 ms, profiles/r04b_ab_fixlist_atomics_small.jsonl.)
+            {
+                const int rem = a.W - x;            // pixels of the group inside the image
+                const uint32_t inside = rem >= 4 ? 0xFu : rem > 0 ? (1u << rem) - 1u : 0u;
+                s_dirty[(c * TH + ty) * (TW / 4) + tx4 / 4] = (uint8_t)(dirty & inside);
+            }
+        }
+        }
+#if !defined(MULUT_VARIANT_nofixlist)    /* (timing-only variant: nothing is listed, flagged sites stay wrong) */
+        __syncthreads();      // every group byte of the tile is written
+        {
+            const int t = opaque_tid(), lane = t & 63, wave = t >> 6;
+            const uint16_t *gb = (const uint16_t *)s_dirty + 3 * t;      // this thread's six group bytes
+            const uint32_t b01 = gb[0], b23 = gb[1], b45 = gb[2];
+            const uint32_t mine = (uint32_t)(__builtin_popcount(b01 & 0x0F0Fu) + __builtin_popcount(b23 & 0x0F0Fu) + __builtin_popcount(b45 & 0x0F0Fu));
+            uint32_t inc = mine;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool d = ((dirty >> i) & 1u) != 0u && x + i < a.W;
-                const unsigned long long dm = __ballot(d);
-                if (dm != 0ull) {
-                    const int lane = (int)(threadIdx.x & 63), lead = __ffsll((long long)dm) - 1;
-                    uint32_t at = 0;
-                    if (lane == lead) at = atomicAdd(a.fix_count, (uint32_t)__popcll(dm));
-                    at = (uint32_t)__shfl((int)at, lead);
-                    if (d) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = (uint32_t)(((n * a.C + c) * a.H + y) * a.W + x + i);
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)inc, o);
+                if (lane >= o) inc += up;
+            }
+            if (lane == 63) s_scan[wave] = inc;
+            __syncthreads();
+            uint32_t wbase = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) {
+                const uint32_t v = s_scan[w];
+                wbase += w < wave ? v : 0u;
+                total += v;
+            }
+            if (total != 0u) {        // workgroup-uniform
+                if (t == 0) s_scan[8] = atomicAdd(a.fix_count, total);
+                __syncthreads();
+                uint32_t at = s_scan[8] + wbase + inc - mine;
+                const uint32_t bytes6[3] = {b01, b23, b45};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const uint32_t bits = (bytes6[k >> 1] >> (8 * (k & 1))) & 0xFu;
+                    if (bits == 0u) continue;
+                    const int g = 6 * t + k, cg = g % (TW / 4), row = (g / (TW / 4)) % TH, c = g / ((TW / 4) * TH);
+                    const uint32_t id0 = (uint32_t)(((n * a.C + c) * a.H + y0 + row) * a.W + x0 + 4 * cg);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if ((bits >> i) & 1u) a.fix_list[at++] = id0 + (uint32_t)i;
                 }
             }
+        }
 #endif
-        }
-        }
         K1_STAMP(3);          // the sites
     }
 #if defined(MULUT_VARIANT_k1prof)
@@ -647,6 +683,7 @@ __global__ void __launch_bounds__(256) stage_u1_fix_kernel(StageArgs a) {
         const int x = (int)(id % (uint32_t)a.W); id /= (uint32_t)a.W;
         const int y = (int)(id % (uint32_t)a.H); id /= (uint32_t)a.H;
         const int c = (int)(id % (uint32_t)a.C), n = (int)(id / (uint32_t)a.C);
+        if (n >= a.N || y < a.oy0 || y >= a.oy1) continue;      // never follow an entry outside the launch (a list bug must show as a wrong pixel, not as a memory fault)
         auto px = [&](int dy, int dx) {
             const int gy = imin(imax(y + dy, ylo), yhi), gx = imin(imax(x + dx, 0), a.W - 1);
             return (int)*view_addr(a.in, n, c, gy, gx);
@@ -687,7 +724,7 @@ static hipError_t launch_u1t_t(const StageArgs &a, const BandArgs &b, unsigned d
     // persist_per_cu > 0: that many persistent workgroups per CU walk XCD-contiguous tile ranges; 0: one workgroup per tile
     const long long want = persist_per_cu > 0 ? (long long)persist_per_cu * num_cus : ntiles;     // (three 512-thread workgroups fit a CU)
     const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
-    const size_t lds = 3 * (size_t)u1t_band_bytes<U>() + kU1tTileBytes + 16;
+    const size_t lds = 3 * (size_t)u1t_band_bytes<U>() + kU1tTileBytes + 16 + kU1tDirtyBytes + 64;
     hipLaunchKernelGGL(stage_u1t_kernel<U>, dim3(grid), dim3(K1T_NT), lds, st, a, b, (uint32_t)detail_per_1024);
     return hipGetLastError();
 }
@@ -727,6 +764,7 @@ __global__ void __launch_bounds__(256) stage_up_fix_site_kernel(StageArgs a) {
         const int x = (int)(id % (uint32_t)a.W); id /= (uint32_t)a.W;
         const int y = (int)(id % (uint32_t)a.H); id /= (uint32_t)a.H;
         const int c = (int)(id % (uint32_t)a.C), n = (int)(id / (uint32_t)a.C);
+        if (n >= a.N || y < a.oy0 || y >= a.oy1) continue;      // (as stage_u1_fix_kernel)
         auto px = [&](int dy, int dx) {
             const int gy = imin(imax(y + dy, ylo), yhi), gx = imin(imax(x + dx, 0), a.W - 1);
             return (int)*view_addr(a.in, n, c, gy, gx);

@@ -662,7 +662,8 @@ __global__ void __launch_bounds__(256) stage_up_fix2_kernel(StageArgs a) {
         // entry: pixel id (n H + y) W + x in the low 30 bits, channel in the top two (3 = every channel)
         const uint32_t ent = a.fix_list[i], id = ent & 0x3FFFFFFFu, only = ent >> 30;
         const int x = (int)(id % (uint32_t)a.W), y = (int)((id / (uint32_t)a.W) % (uint32_t)a.H), n = (int)(id / ((uint32_t)a.W * (uint32_t)a.H));
-        const int c_lo = only == 3u ? 0 : (int)only, c_hi = only == 3u ? a.C : (int)only + 1;
+        if (n >= a.N || y < a.oy0 || y >= a.oy1) continue;      // never follow an entry outside the launch (a list bug must show as a wrong pixel, not as a memory fault)
+        const int c_lo = only == 3u ? 0 : (int)only, c_hi = only == 3u ? imin(a.C, 3) : imin((int)only + 1, a.C);
         for (int c = c_lo; c < c_hi; ++c) {
             s_sum[grp][ln] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -879,8 +880,10 @@ __host__ __device__ constexpr int t2_pat(int pats, int m) { return (pats >> (2 +
 constexpr int kT2W = 16, kT2H = 4;        // a wave's tile: 16 x 4 pixels, one site per lane (192 contiguous output bytes per HR row)
 constexpr int kT2PW = kT2W + 2 * kTubeHaloX, kT2PH = kT2H + 2 * kHalo, kT2Chan = 2 * kT2PH * kT2PW;
 constexpr int kT2WaveTileBytes = 3 * kT2Chan;
-// LDS: [ band s | band d | band y ][ 16 wave images of pixel codes ][ parked output rows of channels 0 and 1 (RGB path) ][ work counter ]
-constexpr int kTube2LdsBytes = 3 * kTubeBandBytes + 16 * kT2WaveTileBytes + 2 * 16 * KB_TW * KB_TH + 16;
+// LDS: [ band s | band d | band y ][ 16 wave images of pixel codes ][ parked output rows of channels 0 and 1 (RGB path) ][ 16 fix-up buffers ][ work counter ]
+constexpr int kT2FixCap = 3 * kT2W * kT2H;      // a wave's fix-up buffer holds the flagged samples of (at least) one whole wave tile
+constexpr int kT2FixOff = 3 * kTubeBandBytes + 16 * kT2WaveTileBytes + 2 * 16 * KB_TW * KB_TH;      // 16 waves x kT2FixCap entries
+constexpr int kTube2LdsBytes = kT2FixOff + 16 * kT2FixCap * 4 + 16;
 static_assert(kTube2LdsBytes <= 160 * 1024, "LDS budget");
 static_assert(KB_TW % kT2W == 0 && KB_TH % kT2H == 0 && (KB_TW / kT2W) * (KB_TH / kT2H) == 16 && KB_TW / kT2W == 4, "16 wave tiles per verdict tile, four across");
 // byte offset (from the window corner) of neighbour K of pattern PAT under rotation R; SIGN -1: rotation R + 2
@@ -1082,6 +1085,22 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
     __syncthreads();          // the only barrier of the kernel
     T2_STAMP(5);
 
+    // the wave's share of the fix-up list in the making (entries in LDS, their number in a scalar register)
+    uint32_t *fix_buf = (uint32_t *)(smem + kT2FixOff) + wave * kT2FixCap;
+    uint32_t fix_have = 0u;
+    auto fix_flush = [&]() {
+        if (fix_have == 0u) return;      // wave-uniform
+        // called where lanes outside the image are masked off: the copy is shared out among the ACTIVE lanes
+        const unsigned long long act = __ballot(true);
+        const uint32_t rank = (uint32_t)__popcll(act & ((1ull << (threadIdx.x & 63)) - 1ull)), nact = (uint32_t)__popcll(act);
+        uint32_t at = 0u;
+        if (rank == 0u) at = atomicAdd(a.fix_count, fix_have);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the entries other lanes of this wave stored (LDS serves a wave's operations in order)
+        for (uint32_t i = rank; i < fix_have; i += nact) a.fix_list[at + i] = fix_buf[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // read before the buffer is filled again
+        fix_have = 0u;
+    };
     uint32_t pix[PER4];
     int item = grab();
     fetch(item, pix);
@@ -1217,22 +1236,21 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                 const uint32_t oR[4] = {r.x, r.y, r.z, r.w}, oG[4] = {g.x, g.y, g.z, g.w};
                 store_rgb<4>(a, n, y, x, oR, oG, o);
             }
-            // dirty samples (pixel, channel) go on the fix-up list: one atomic per wave and channel (rare), compacted by lane rank
+            // dirty samples (pixel, channel) are collected in the wave's LDS buffer and appended to the fix-up list when it is full (and
+            // when the wave runs out of work): one memory-side atomic per ~190 flagged samples instead of one per wave tile and channel
 #if defined(MULUT_VARIANT_nofixlist)    /* timing-only: nothing is listed (flagged samples stay wrong) */
             if (dmask == 0xFFFFFFFFu) a.fix_list[0] = 0u;
 #else
             if (__ballot(dmask != 0u) != 0ull) {
                 const uint32_t pixel_id = (uint32_t)((n * a.H + y) * a.W + x);
-                for (int c = 0; c < a.C; ++c) {
-                    const bool d = ((dmask >> c) & 1u) != 0u;
-                    const unsigned long long dm = __ballot(d);
-                    if (dm == 0ull) continue;
-                    const int lane = (int)(threadIdx.x & 63);
-                    uint32_t at = 0;
-                    if (lane == __ffsll((long long)dm) - 1) at = atomicAdd(a.fix_count, (uint32_t)__popcll(dm));
-                    at = (uint32_t)__shfl((int)at, __ffsll((long long)dm) - 1);
-                    if (d) a.fix_list[at + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = pixel_id | ((uint32_t)c << 30);
-                }
+                const unsigned long long m0 = __ballot((dmask & 1u) != 0u), m1 = __ballot((dmask & 2u) != 0u), m2 = __ballot((dmask & 4u) != 0u);
+                const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2);
+                if (fix_have + n0 + n1 + n2 > (uint32_t)kT2FixCap) fix_flush();
+                const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+                if (dmask & 1u) fix_buf[fix_have + (uint32_t)__popcll(m0 & below)] = pixel_id;
+                if (dmask & 2u) fix_buf[fix_have + n0 + (uint32_t)__popcll(m1 & below)] = pixel_id | (1u << 30);
+                if (dmask & 4u) fix_buf[fix_have + n0 + n1 + (uint32_t)__popcll(m2 & below)] = pixel_id | (2u << 30);
+                fix_have += n0 + n1 + n2;
             }
 #endif
         }
@@ -1241,6 +1259,7 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
         T2_STAMP(4);       // next tile's pixel codes into LDS (waits for its fetch)
         item = nxt_item;
     }
+    fix_flush();
 #if defined(MULUT_VARIANT_t2prof)
     if (a.dbg && (threadIdx.x & 63) == 0) {
         atomicAdd(a.dbg + 0, (unsigned long long)t_ph0); atomicAdd(a.dbg + 1, (unsigned long long)t_ph1); atomicAdd(a.dbg + 2, (unsigned long long)t_ph2);
