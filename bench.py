@@ -395,6 +395,17 @@ def main():
             rec["config"]["strips_gather"] = strips
         if extra:
             rec["config"]["other_configs"] = extra
+        if dist_on:
+            # what a scaling record must answer at the top level: did the collective backend see N ranks, and what crossed the links
+            rec["backend"] = "rccl (torch.distributed 'nccl')" if backend == "nccl" else "%s (rehearsal: strips travel through host memory)" % backend
+            rec["ranks_in_group"] = torch.distributed.get_world_size()
+            rec["scaling_note"] = ("value = frames sharded over the ranks, no data-path collective (weak); strips_rotate_value = config 3, every LR 2160x3840 "
+                                   "frame cut into one strip per rank (+halo), HR strips exchanged point to point, frame n assembled on rank n mod N (strong)")
+            if strips and "rotate" in strips:
+                rec["strips_rotate_value"] = strips["rotate"]["value"]
+                rec["strips_single_root_value"] = strips["single_root"]["value"]
+                rec["exchanged_bytes_per_step"] = strips["rotate"]["exchanged_bytes_per_step"]
+                rec["max_bytes_into_one_rank_per_step"] = strips["rotate"]["max_bytes_into_one_rank_per_step"]
         print(json.dumps(rec), flush=True)
     if dist_on:
         torch.distributed.destroy_process_group()

@@ -536,6 +536,18 @@ MULUT_HD uint32_t slab_rev_bytes(uint32_t x) { return (x >> 24) | ((x >> 8) & 0x
 MULUT_HD uint32_t slab_rev_odd_bytes(uint32_t x) { return ((x >> 16) & 0xFFu) | ((x & 0xFFu) << 16); }
 #endif
 MULUT_HD uint32_t slab_even_sums(uint32_t F, uint32_t H) { return pk_mad(H, pk_dup(0xFF00u), F); }
+// Round 4: the second accumulator takes the dword shifted right by 8 bits -- one full-rate 32-bit shift instead of a half-rate byte
+// permute per dword and row:
+//   F += x * w          fields (b0 + 256 b1, b2 + 256 b3) * w
+//   G += (x >> 8) * w   fields (b1 + 256 b2, b3) * w
+// With E_i / O_i the sums of the even / odd bytes:  F = (E0 + 256 O1, E2 + 256 O3),  G = (O1 + 256 E2, O3)  (mod 2^16 per field), so
+//   E = F - 256 G = (E0, E2)                  (one packed multiply-add: 256 * 256 E2 leaves the field)
+//   O = G - ((256 E2 mod 2^16), 0) = (O1, O3)
+// exact while every true sum is below 2^16 (as for slab_even_sums).
+MULUT_HD void slab_split_sums(uint32_t F, uint32_t G, uint32_t &even, uint32_t &odd) {
+    even = pk_mad(G, pk_dup(0xFF00u), F);
+    odd = pk_sub(G, (even >> 8) & 0x0000FF00u);
+}
 
 // ---- full-table pairs for 1-byte rows (first-stage kernel on detailed tiles) ------------------------------
 // Rotations r / r + 2 of one site in packed halves against the WHOLE table (row index A 4913 + B 289 + C 17 + D).  The

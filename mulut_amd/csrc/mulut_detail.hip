@@ -238,7 +238,8 @@ __global__ void __launch_bounds__(256) detail_fill_kernel(StageArgs a, DetailArg
 }
 
 
-// accumulators of one sample: raw (F) and odd-byte (H) sums of the rotation pairs (0, 2) and (1, 3)
+// accumulators of one sample: sums of the raw dwords (F) and of the dwords shifted right by one byte (G) of the rotation pairs (0, 2)
+// and (1, 3) -- mulut_core.h slab_split_sums
 struct SlabAcc {
     uint32_t F02[4], H02[4], F13[4], H13[4];
     __device__ __forceinline__ void clear() {
@@ -250,17 +251,17 @@ struct SlabAcc {
         const uint32_t rd[4] = {row.x, row.y, row.z, row.w};
         static_for<0, 4>([&](auto K) {
             constexpr int k = K;
-            if constexpr (R == 0) { pk_mac<HALF, false>(F02[k], rd[k], wpk); pk_mac<HALF, false>(H02[k], slab_odd_bytes(rd[k]), wpk); }
-            if constexpr (R == 1) { pk_mac<HALF, false>(F13[k], rd[k], wpk); pk_mac<HALF, false>(H13[k], slab_odd_bytes(rd[k]), wpk); }
-            if constexpr (R == 2) { pk_mac<HALF, false>(F02[3 - k], slab_rev_bytes(rd[k]), wpk); pk_mac<HALF, false>(H02[3 - k], slab_rev_odd_bytes(rd[k]), wpk); }
-            if constexpr (R == 3) { pk_mac<HALF, false>(F13[3 - k], slab_rev_bytes(rd[k]), wpk); pk_mac<HALF, false>(H13[3 - k], slab_rev_odd_bytes(rd[k]), wpk); }
+            if constexpr (R == 0) { pk_mac<HALF, false>(F02[k], rd[k], wpk); pk_mac<HALF, false>(H02[k], rd[k] >> 8, wpk); }
+            if constexpr (R == 1) { pk_mac<HALF, false>(F13[k], rd[k], wpk); pk_mac<HALF, false>(H13[k], rd[k] >> 8, wpk); }
+            if constexpr (R == 2) { const uint32_t rv = slab_rev_bytes(rd[k]); pk_mac<HALF, false>(F02[3 - k], rv, wpk); pk_mac<HALF, false>(H02[3 - k], rv >> 8, wpk); }
+            if constexpr (R == 3) { const uint32_t rv = slab_rev_bytes(rd[k]); pk_mac<HALF, false>(F13[3 - k], rv, wpk); pk_mac<HALF, false>(H13[3 - k], rv >> 8, wpk); }
         });
     }
     __device__ __forceinline__ void to_fields(RotAcc<4> &r) const {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            r.lo02[k] = slab_even_sums(F02[k], H02[k]); r.hi02[k] = H02[k];
-            r.lo13[k] = slab_even_sums(F13[k], H13[k]); r.hi13[k] = H13[k];
+            slab_split_sums(F02[k], H02[k], r.lo02[k], r.hi02[k]);
+            slab_split_sums(F13[k], H13[k], r.lo13[k], r.hi13[k]);
         }
     }
 };
@@ -277,11 +278,10 @@ __device__ __forceinline__ uint32_t mad16_half(uint32_t x, uint32_t acc) {
 // LDS byte addresses of rows 0..3 of the pass in half HALF: 16 * (running sum of the path's unit steps); row 4 = row 0 + kSlabAll * 16
 template <int HALF>
 __device__ __forceinline__ void slab_row_addrs(const SlabPair &sp, uint32_t (&ad)[4]) {
-    ad[0] = HALF ? (sp.base >> 16) : (sp.base & 0xFFFFu);
+    // one v_mad_u32_u16 per row: (the pass's half of the packed unit step) * 16 + the previous row's address -- extract, scale and add at once
+    ad[0] = mad16_half<HALF>(sp.base, 0u);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) ad[j + 1] = add_word<HALF>(ad[j], sp.step[j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ad[j] <<= 4;
+    for (int j = 0; j < 3; ++j) ad[j + 1] = mad16_half<HALF>(sp.step[j], ad[j]);
 }
 template <int J>
 __device__ __forceinline__ uint4 slab_row(const uint32_t (&ad)[4]) {

@@ -219,11 +219,17 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant) {
 // (stage_u1w_kernel, list mode) through a tile list.  Both lists live in device memory; nothing syncs with the host.
 // LDS: [ band s | band d | band y : 4,176 B each ][ image tile: C x 68 x 68 pixel codes ][ counters ]
 // ------------------------------------------------------------------------------------------
-constexpr int K1T_TW = 64, K1T_TH = 64, K1T_NT = 512;      // 512 threads take the tile's 64 x 64 sites in two halves of 32 rows
+constexpr int K1T_TW = 64, K1T_TH = 64;
+// Threads per workgroup (a thread owns four adjacent pixels of a row: 1024 take the 64 x 64 tile at once, 512 in two halves of 32 rows) and
+// waves per SIMD.  The instance with the shipped mode list compiled in needs 59 VGPRs: two 1024-thread workgroups share a CU at 8 waves per
+// SIMD (the half-rate instruction class issues at 2.62 cycles per instruction and SIMD there, 2.83 at 6: profiles/r01_ubench_valu_issue_cost.txt).
+// The run-time-list instances need 80: three 512-thread workgroups, 6 waves per SIMD.
+__host__ __device__ constexpr int u1t_threads(int U, int pats) { return (U == 1 && pats != 0) ? 1024 : 512; }
+__host__ __device__ constexpr int u1t_waves(int U, int pats) { return (U == 1 && pats != 0) ? 8 : 6; }
 constexpr int K1T_PW = K1T_TW + 2 * kHalo, K1T_PH = K1T_TH + 2 * kHalo;
 constexpr int kU1tTileBytes = 3 * K1T_PH * K1T_PW * 2;
 constexpr int kU1tDirtyBytes = 3 * K1T_TH * (K1T_TW / 4);          // one byte per four-pixel group of the tile
-static_assert(kU1tDirtyBytes == 6 * K1T_NT, "the list pass gives every thread six group bytes");
+static_assert(kU1tDirtyBytes % 1024 == 0, "the list pass gives every thread the same number of group bytes");
 
 // accumulators of one site: u == 1 one int32; u == 2 two rotation-pair sets of four 16-bit fields (value + 128 rows, as
 // the u == 4 kernels: a02 holds rotations 0 and 2 -- the latter added in reversed element order -- a13 rotations 1 and 3)
@@ -238,6 +244,19 @@ __device__ __forceinline__ uint2 lds_u64(uint32_t addr) {
     const u32x2 v = *(const __attribute__((address_space(3))) u32x2 *)(uintptr_t)addr;
     return make_uint2(v.x, v.y);
 }
+// (a & 0x0000FFFF) | (b & 0xFFFF0000) as ONE full-rate instruction: v_bitop3_b32 with the bit-field-insert truth table (mask, a, b -> 0xCA).
+// The compiler's own choice for this expression is v_bfi_b32, which issues at the half rate of the packed / three-operand class
+// (profiles/r01_ubench_valu_issue_cost.txt: BFIOR 1.49 vs 2.83 cycles per instruction and SIMD at 6 waves).
+__device__ __forceinline__ uint32_t halves_lo_hi(uint32_t a, uint32_t b) {
+    uint32_t r;
+    const uint32_t m = 0x0000FFFFu;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "s"(m), "v"(a), "v"(b));
+    return r;
+}
+// mode list as a compile-time constant (the encoding of stage_tube2_kernel: M | p0 << 2 | p1 << 4 | p2 << 6, M <= 3), 0 = read at run time
+__host__ __device__ constexpr int u1t_modes(int pats) { return pats & 3; }
+__host__ __device__ constexpr int u1t_pat(int pats, int m) { return (pats >> (2 + 2 * m)) & 3; }
+constexpr int kU1tPatsSDY = 3 | (0 << 2) | (1 << 4) | (2 << 6);
 template <int U> __host__ __device__ constexpr int u1t_band_bytes() { return U == 1 ? kTube1BandBytes : kTube2BandBytes; }
 
 // rotations R and R + 2 of the pixel at window column I + 2, pattern PAT
@@ -269,14 +288,23 @@ __device__ __forceinline__ void u1t_pair(const uint32_t (&win)[5][NW], uint32_t 
         for (int j = 0; j < 5; ++j) {
             // LDS addresses as plain integers (dynamic LDS starts at 0 -- checked at kernel entry): going through the
             // `smem` symbol would cost one v_add of a link-time zero per read
+#if defined(MULUT_VARIANT_k1nolds)      /* timing-only: no table reads (wrong results): what the index math and the dot products cost alone */
+            xa[j] = aa[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4));
+            xb2[j] = ab[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4));
+#else
             xa[j] = lds_u32(aa[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
             xb2[j] = lds_u32(ab[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
+#endif
         }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             typedef short s16x2 __attribute__((ext_vector_type(2)));
-            const uint32_t t = (xa[j] & 0x0000FFFFu) | (xb2[j] & 0xFFFF0000u);     // value of pass A | value of pass B
+            const uint32_t t = halves_lo_hi(xa[j], xb2[j]);     // value of pass A | value of pass B
+#if defined(MULUT_VARIANT_k1pkmad)
+            acc.v = (int)pk_mad(t, bp.w[j], (uint32_t)acc.v);      // packed 16-bit sums of the A / B passes (|sum| <= 16 passes x 2048)
+#else
             acc.v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, bp.w[j]), acc.v, false);
+#endif
         }
     } else {
         uint2 xa[5], xb2[5];
@@ -311,22 +339,39 @@ __device__ __forceinline__ void u1t_mode(const uint32_t (&win)[5][3], uint32_t &
 }
 
 // one pixel: all modes, then the byte (u == 1) or the 2 x 2 block as four bytes, row-major (u == 2)
-template <int U, int I>
-__device__ __forceinline__ uint32_t u1t_pixel(const StageArgs &a, const uint32_t (&win)[5][3]) {
+// PATS != 0: the mode list is a compile-time constant -- the passes of a pixel are straight-line code, no scalar loads of the pattern
+// offsets, no branches (the run-time form reads a.di / a.dj from the kernel arguments per mode and pixel: two s_load + s_waitcnt
+// lgkmcnt(0) in the hot loop, and its three pattern bodies share tails through extra address adds).  PATS == 0: `pats_rt` holds
+// the patterns of the list, two bits per mode.
+template <int U, int I, int PATS>
+__device__ __forceinline__ uint32_t u1t_pixel(const StageArgs &a, uint32_t pats_rt, const uint32_t (&win)[5][3]) {
     U1tAcc<U> acc;
     acc.clear();
     // anchor terms, the same for every mode and rotation of the pixel
     const uint32_t ca_pk = win_pair<2, I + 2, 2, I + 2, 3>(win);
     uint32_t k0 = tube1_key(ca_pk, kTubeSA << (U == 1 ? 2 : 3));
     const uint32_t base_a = pk_mad(ca_pk, pk_dup(16 * kTubeSA), 0u);
-    for (int mv = 0; mv < a.M; ++mv) {
-        const int m = __builtin_amdgcn_readfirstlane(mv);
-        const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
-        if (pat == 0) u1t_mode<U, 0, I>(win, k0, base_a, acc);
-        else if (pat == 1) u1t_mode<U, 1, I>(win, k0, base_a, acc);
-        else u1t_mode<U, 2, I>(win, k0, base_a, acc);
+    if constexpr (PATS != 0) {
+        static_for<0, u1t_modes(PATS)>([&](auto MI) {
+            constexpr int m = MI;
+            if constexpr (m > 0) {      // one mode at a time (register budget)
+                if constexpr (U == 1) asm volatile("" : "+v"(acc.v), "+v"(k0));
+                else asm volatile("" : "+v"(acc.a02[0]), "+v"(k0));
+            }
+            u1t_mode<U, u1t_pat(PATS, m), I>(win, k0, base_a, acc);
+        });
+    } else {
+        for (int mv = 0; mv < a.M; ++mv) {
+            const int pat = (int)((pats_rt >> (2 * mv)) & 3u);      // scalar
+            if (pat == 0) u1t_mode<U, 0, I>(win, k0, base_a, acc);
+            else if (pat == 1) u1t_mode<U, 1, I>(win, k0, base_a, acc);
+            else u1t_mode<U, 2, I>(win, k0, base_a, acc);
+        }
     }
     if constexpr (U == 1) {
+#if defined(MULUT_VARIANT_k1pkmad)
+        acc.v = ((int)((uint32_t)acc.v << 16) >> 16) + (acc.v >> 16);
+#endif
         if (a.use_fma)       // wave-uniform: fused float epilogue proven exact; v_cvt_pk_u8_f32 rounds to nearest even and saturates
             return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)acc.v, a.inv_d, a.epi_c), 0u, 0u);
         return rhe_clip_u8(acc.v + a.bias_num, a.div);
@@ -382,24 +427,26 @@ __device__ __forceinline__ uint32_t far_apart(uint32_t a, uint32_t b) {
     return ((hi - lo) & 0xFFFEu) ? 1u : 0u;
 }
 
-#define K1T_WAVES 6      // 80 VGPRs: three 512-thread workgroups per CU (8 waves per SIMD would mean 64 VGPRs and spills in the pair loop)
-template <int U>
-__global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs a, BandArgs b, uint32_t detail_per_1024) {
-    constexpr int TW = K1T_TW, TH = K1T_TH, NT = K1T_NT, PW = K1T_PW, PH = K1T_PH;
+template <int U, int PATS>
+__global__ void __launch_bounds__(u1t_threads(U, PATS), u1t_waves(U, PATS)) stage_u1t_kernel(StageArgs a, BandArgs b, uint32_t detail_per_1024) {
+    constexpr int TW = K1T_TW, TH = K1T_TH, NT = u1t_threads(U, PATS), PW = K1T_PW, PH = K1T_PH;
     constexpr int BB = u1t_band_bytes<U>();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *s_tile = smem + 3 * BB;
     uint32_t *s_cnt = (uint32_t *)(smem + 3 * BB + kU1tTileBytes);     // [0] detailed groups, [1] groups looked at
     uint8_t *s_dirty = smem + 3 * BB + kU1tTileBytes + 16;              // [channel][tile row][16 four-pixel groups]: dirty bit per pixel of the group
-    uint32_t *s_scan = (uint32_t *)(s_dirty + kU1tDirtyBytes);          // [0..7] flagged sites per wave, [8] where the tile's entries start in the fix-up list
+    uint32_t *s_scan = (uint32_t *)(s_dirty + kU1tDirtyBytes);          // [0..NT/64) flagged sites per wave, [16] where the tile's entries start in the fix-up list
     if (lds_addr_of(smem) != 0u) __builtin_trap();      // the band reads assume the dynamic LDS block starts at address 0 (no static LDS here): fail loudly, never skip the work
 
+    uint32_t pats_rt = 0u;       // pattern of mode m in bits 2m, 2m + 1 (scalar; kMaxModes = 8 modes fit)
     for (int m = 0; m < a.M; ++m) {
         const int pat = a.dj[m][0] == 2 ? 1 : a.di[m][0] == 1 ? 2 : 0;
+        pats_rt |= (uint32_t)pat << (2 * m);
         const uint32_t *src = (const uint32_t *)b.band[m];
         uint32_t *dst = (uint32_t *)(smem + pat * BB);
         for (int i = (int)threadIdx.x; i < BB / 4; i += NT) dst[i] = src[i];
     }
+    pats_rt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pats_rt);
     const int ntiles = a.N * a.tiles_x * a.tiles_y;
     const int G = gridDim.x;
     const bool by_xcd = (G & 7) == 0;
@@ -420,11 +467,18 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
         return t;
     };
 
-#if defined(MULUT_VARIANT_k1prof)   /* probe build: shader-clock ticks per phase, summed over all waves into the context's probe buffer (words 16..19) */
-    uint32_t t_prev = (uint32_t)__builtin_amdgcn_s_memtime(), t_ph0 = 0, t_ph1 = 0, t_ph2 = 0, t_ph3 = 0;
+#if defined(MULUT_VARIANT_k1prof) || defined(MULUT_VARIANT_k1prof2)   /* probe build: shader-clock ticks per phase, summed over all waves into the context's probe buffer (words 16..19) */
+    const unsigned long long t_first = __builtin_amdgcn_s_memtime(), r_first = __builtin_amdgcn_s_memrealtime();
+    uint32_t t_prev = (uint32_t)t_first, t_ph0 = 0, t_ph1 = 0, t_ph2 = 0, t_ph3 = 0, t_ph4 = 0, t_ph5 = 0, t_ph6 = 0, t_ph7 = 0;
+#if defined(MULUT_VARIANT_k1prof2)      /* the sites phase in four parts (words 24..27) instead of as one */
+#define K1_STAMP2(PH) K1_STAMP(PH)
+#else
+#define K1_STAMP2(PH) do { } while (0)
+#endif
 #define K1_STAMP(PH) do { const uint32_t t_now = (uint32_t)__builtin_amdgcn_s_memtime(); t_ph##PH += t_now - t_prev; t_prev = t_now; } while (0)
 #else
 #define K1_STAMP(PH) do { } while (0)
+#define K1_STAMP2(PH) do { } while (0)
 #endif
     for (int tile = first; tile < last; tile += step) {
         int n, y0, x0;
@@ -560,6 +614,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                 dirty = u1t_dirty(win8);
                 asm volatile("" : "+v"(dirty));     // computed HERE: sunk below the pixel loop, its 20 window registers would be parked in scratch
             }
+            K1_STAMP2(4);
             uint32_t packed = 0;
             // two pixels per step of a real loop: their 5 x 6 window is re-read (dword-aligned), nothing of a later step
             // can be scheduled into an earlier one
@@ -575,9 +630,9 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                 for (int q = 0; q < 5; ++q) {
                     win[q][0] = row[q * (PW / 2)]; win[q][1] = row[q * (PW / 2) + 1]; win[q][2] = row[q * (PW / 2) + 2];
                 }
-                uint32_t b0 = u1t_pixel<U, 0>(a, win);
+                uint32_t b0 = u1t_pixel<U, 0, PATS>(a, pats_rt, win);
                 asm volatile("" : "+v"(b0), "+v"(win[2][1]));       // the second pixel starts after the first is done
-                const uint32_t b1 = u1t_pixel<U, 1>(a, win);
+                const uint32_t b1 = u1t_pixel<U, 1, PATS>(a, pats_rt, win);
                 if constexpr (U == 1) {
                     packed |= (b0 | (b1 << 8)) << (16 * it);
                 } else {
@@ -599,6 +654,7 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                     }
                 }
             }
+            K1_STAMP2(5);
             int ty, tx4;
             coords(ty, tx4);
             const int y = y0 + ty, x = x0 + tx4;
@@ -620,15 +676,21 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                 const uint32_t inside = rem >= 4 ? 0xFu : rem > 0 ? (1u << rem) - 1u : 0u;
                 s_dirty[(c * TH + ty) * (TW / 4) + tx4 / 4] = (uint8_t)(dirty & inside);
             }
+            K1_STAMP2(6);
         }
         }
 #if !defined(MULUT_VARIANT_nofixlist)    /* (timing-only variant: nothing is listed, flagged sites stay wrong) */
         __syncthreads();      // every group byte of the tile is written
         {
             const int t = opaque_tid(), lane = t & 63, wave = t >> 6;
-            const uint16_t *gb = (const uint16_t *)s_dirty + 3 * t;      // this thread's six group bytes
-            const uint32_t b01 = gb[0], b23 = gb[1], b45 = gb[2];
-            const uint32_t mine = (uint32_t)(__builtin_popcount(b01 & 0x0F0Fu) + __builtin_popcount(b23 & 0x0F0Fu) + __builtin_popcount(b45 & 0x0F0Fu));
+            constexpr int GB = kU1tDirtyBytes / NT;       // group bytes per thread: 6 (512 threads) or 3 (1024)
+            uint32_t bytes = 0u, mine = 0u;               // this thread's group nibbles, four bits each
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const uint32_t v = (uint32_t)s_dirty[GB * t + k] & 0xFu;
+                bytes |= v << (4 * k);
+                mine += (uint32_t)__builtin_popcount(v);
+            }
             uint32_t inc = mine;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -645,15 +707,14 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
                 total += v;
             }
             if (total != 0u) {        // workgroup-uniform
-                if (t == 0) s_scan[8] = atomicAdd(a.fix_count, total);
+                if (t == 0) s_scan[16] = atomicAdd(a.fix_count, total);
                 __syncthreads();
-                uint32_t at = s_scan[8] + wbase + inc - mine;
-                const uint32_t bytes6[3] = {b01, b23, b45};
+                uint32_t at = s_scan[16] + wbase + inc - mine;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const uint32_t bits = (bytes6[k >> 1] >> (8 * (k & 1))) & 0xFu;
+                for (int k = 0; k < GB; ++k) {
+                    const uint32_t bits = (bytes >> (4 * k)) & 0xFu;
                     if (bits == 0u) continue;
-                    const int g = 6 * t + k, cg = g % (TW / 4), row = (g / (TW / 4)) % TH, c = g / ((TW / 4) * TH);
+                    const int g = GB * t + k, cg = g % (TW / 4), row = (g / (TW / 4)) % TH, c = g / ((TW / 4) * TH);
                     const uint32_t id0 = (uint32_t)(((n * a.C + c) * a.H + y0 + row) * a.W + x0 + 4 * cg);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -662,12 +723,18 @@ __global__ void __launch_bounds__(K1T_NT, K1T_WAVES) stage_u1t_kernel(StageArgs 
             }
         }
 #endif
+        K1_STAMP2(7);
         K1_STAMP(3);          // the sites
     }
-#if defined(MULUT_VARIANT_k1prof)
+#if defined(MULUT_VARIANT_k1prof) || defined(MULUT_VARIANT_k1prof2)
     if (a.dbg && (threadIdx.x & 63) == 0) {
         atomicAdd(a.dbg + 16, (unsigned long long)t_ph0); atomicAdd(a.dbg + 17, (unsigned long long)t_ph1);
         atomicAdd(a.dbg + 18, (unsigned long long)t_ph2); atomicAdd(a.dbg + 19, (unsigned long long)t_ph3);
+        atomicAdd(a.dbg + 20, __builtin_amdgcn_s_memtime() - t_first);          // wave lifetime in shader-clock ticks ...
+        atomicAdd(a.dbg + 21, __builtin_amdgcn_s_memrealtime() - r_first);      // ... and in 100 MHz ticks: their ratio is the in-kernel clock
+        atomicAdd(a.dbg + 22, 1ull);
+        atomicAdd(a.dbg + 24, (unsigned long long)t_ph4); atomicAdd(a.dbg + 25, (unsigned long long)t_ph5);
+        atomicAdd(a.dbg + 26, (unsigned long long)t_ph6); atomicAdd(a.dbg + 27, (unsigned long long)t_ph7);
     }
 #endif
 #undef K1_STAMP
@@ -711,21 +778,26 @@ __global__ void __launch_bounds__(256) stage_u1_fix_kernel(StageArgs a) {
     }
 }
 
+
 void stage_u1t_tile(int &tw, int &th) { tw = K1T_TW; th = K1T_TH; }
 
 template <int U>
 static hipError_t launch_u1t_t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st) {
+    // the shipped mode list gets the instance with its passes in straight-line code
+    const bool sdy = a.M == 3 && a.di[0][0] == 0 && a.dj[0][0] == 1 && a.dj[1][0] == 2 && a.di[2][0] == 1 && a.dj[2][0] == 1;
+    auto kern = sdy ? stage_u1t_kernel<U, kU1tPatsSDY> : stage_u1t_kernel<U, 0>;
     {
-        const hipError_t e = raise_lds_limit((const void *)stage_u1t_kernel<U>, 80 * 1024);
+        const hipError_t e = raise_lds_limit((const void *)kern, 80 * 1024);
         if (e != hipSuccess) return e;
     }
     const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return hipErrorInvalidValue;
     // persist_per_cu > 0: that many persistent workgroups per CU walk XCD-contiguous tile ranges; 0: one workgroup per tile
-    const long long want = persist_per_cu > 0 ? (long long)persist_per_cu * num_cus : ntiles;     // (three 512-thread workgroups fit a CU)
+    const int threads = sdy ? u1t_threads(U, kU1tPatsSDY) : u1t_threads(U, 0);
+    const long long want = persist_per_cu > 0 ? (long long)persist_per_cu * num_cus : ntiles;
     const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
-    const size_t lds = 3 * (size_t)u1t_band_bytes<U>() + kU1tTileBytes + 16 + kU1tDirtyBytes + 64;
-    hipLaunchKernelGGL(stage_u1t_kernel<U>, dim3(grid), dim3(K1T_NT), lds, st, a, b, (uint32_t)detail_per_1024);
+    const size_t lds = 3 * (size_t)u1t_band_bytes<U>() + kU1tTileBytes + 16 + kU1tDirtyBytes + 80;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a, b, (uint32_t)detail_per_1024);
     return hipGetLastError();
 }
 

@@ -251,7 +251,7 @@ extern "C" long emul_check_slab_pair(int step) {
     uint32_t rng = 12345u;
     auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
     for (int trial = 0; trial < 2000; ++trial) {
-        uint32_t F[4] = {0, 0, 0, 0}, H[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        uint32_t F[4] = {0, 0, 0, 0}, H[4] = {0, 0, 0, 0}, G[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
         const bool extreme = trial < 4;
         for (int pass = 0; pass < 16; ++pass) {      // four modes x (rotation r, rotation r + 2) x two visits: the merged field bound
             const bool rev = (pass & 1) != 0;
@@ -265,11 +265,13 @@ extern "C" long emul_check_slab_pair(int step) {
                     if (!rev) {
                         F[k] = pk_mad(row, wpk, F[k]);
                         H[k] = pk_mad(slab_odd_bytes(row), wpk, H[k]);
+                        G[k] = pk_mad(row >> 8, wpk, G[k]);
                         lo[k] += (row & 0x00FF00FFu) * (uint32_t)wj;
                         hi[k] += ((row >> 8) & 0x00FF00FFu) * (uint32_t)wj;
                     } else {
                         F[3 - k] = pk_mad(slab_rev_bytes(row), wpk, F[3 - k]);
                         H[3 - k] = pk_mad(slab_rev_odd_bytes(row), wpk, H[3 - k]);
+                        G[3 - k] = pk_mad(slab_rev_bytes(row) >> 8, wpk, G[3 - k]);
                         lo[3 - k] += bytes_3_1(row) * (uint32_t)wj;
                         hi[3 - k] += bytes_2_0(row) * (uint32_t)wj;
                     }
@@ -278,6 +280,11 @@ extern "C" long emul_check_slab_pair(int step) {
         }
         for (int k = 0; k < 4; ++k)
             if (slab_even_sums(F[k], H[k]) != lo[k] || H[k] != hi[k]) ++bad;
+        for (int k = 0; k < 4; ++k) {      // the shifted-dword form of round 4
+            uint32_t ev, od;
+            slab_split_sums(F[k], G[k], ev, od);
+            if (ev != lo[k] || od != hi[k]) ++bad;
+        }
     }
     return bad;
 }

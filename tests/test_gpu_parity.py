@@ -554,6 +554,9 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     sg = rec["config"]["strips_gather"]
     assert sg["ranks_in_group"] == 2 and sg["single_root"]["value"] > 0 and sg["rotate"]["value"] > 0
+    # the same facts at the top level of the N > 1 record: the group size the backend saw, the backend, the bytes that crossed the links
+    assert rec["ranks_in_group"] == 2 and rec["backend"].startswith("gloo") and rec["scaling"] == "weak"
+    assert rec["strips_rotate_value"] == sg["rotate"]["value"] and rec["exchanged_bytes_per_step"] == sg["rotate"]["exchanged_bytes_per_step"] > 0
     assert sg["rotate"]["max_bytes_into_one_rank_per_step"] * 2 == sg["single_root"]["max_bytes_into_one_rank_per_step"]
 
 

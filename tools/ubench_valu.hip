@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -96,13 +97,23 @@
 #define A_PKADDF16(D) "v_pk_add_f16 " D ", " D ", %8\n"
 #define A_PKFMAF16(D) "v_pk_fma_f16 " D ", " D ", %8, %9\n"
 #define A_BFIOR(D) "v_bitop3_b32 " D ", " D ", %8, %9 bitop3:0xc8\n"
+#define A_DOT2C(D) "v_dot2c_i32_i16 " D ", %8, %9\n"
+#define A_DOT2(D) "v_dot2_i32_i16 " D ", %8, %9, " D "\n"
+#define A_MADI16(D) "v_mad_i32_i16 " D ", %8, %9, " D " op_sel:[1,1,0,0]\n"
+#define A_MADU16(D) "v_mad_u32_u16 " D ", %8, 16, " D " op_sel:[1,0,0,0]\n"
+#define A_SDWAB(D) "v_add_u32_sdwa " D ", " D ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n"
+#define A_PKSHR(D) "v_pk_lshrrev_b16 " D ", 12, " D " op_sel_hi:[0,1]\n"
+#define A_PKSUB(D) "v_pk_sub_u16 " D ", " D ", %8\n"
+#define A_CVTI16(D) "v_cvt_f32_i32_sdwa " D ", sext(" D ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n"
+#define A_PKMADSEL(D) "v_pk_mad_u16 " D ", %8, %9, " D " op_sel:[1,1,0] op_sel_hi:[0,1,1]\n"
 
 #define OPS(X)                                                                                                       \
     X(ADD) X(AND) X(LSHR) X(MIN) X(MAX) X(MIN3) X(MED3) X(MAD24) X(MUL24) X(MULLO) X(MULHI) X(PERM) X(DOT4) X(PKMAD)   \
     X(PKMIN) X(PKADD) X(BFE) X(LSHLOR) X(ANDOR) X(ADD3) X(LSHLADD) X(SUBSDWA) X(CVTF) X(CVTFSDWA) X(RNDNE) X(MULF)    \
     X(FMA) X(CVTPK) X(ALIGN) X(CNDMASK) X(MOV) X(XAD) X(MADI24) X(BFI) X(SAD) X(MQSAD)              \
     X(MINF) X(MAXF) X(ADDF) X(SUBF) X(MED3F) X(MIN3F) X(CVTU) X(CVTUB0) X(FLOORF) X(FRACTF) X(OR) X(XOR) X(LSHL) X(SUB) X(ASHR)   \
-    X(MINI) X(MINU16) X(ADDU16) X(MULF16) X(MINF16) X(PKMINF16) X(PKADDF16) X(PKFMAF16) X(BFIOR)
+    X(MINI) X(MINU16) X(ADDU16) X(MULF16) X(MINF16) X(PKMINF16) X(PKADDF16) X(PKFMAF16) X(BFIOR) \
+    X(DOT2C) X(DOT2) X(MADI16) X(MADU16) X(SDWAB) X(PKSHR) X(PKSUB) X(CVTI16) X(PKMADSEL)
 
 #define MK(N) DEFKERNEL(N, A_##N)
 OPS(MK)
@@ -161,7 +172,7 @@ struct Ent { const char *name; kfn fn; };
 #define ENTD(N) {"dep_" #N, d_##N},
 static Ent ents[] = {OPS(ENT) DEPOPS(ENTD) {"MIXA", k_MIXA}, {"MIXB", k_MIXB}, {"MIXC", k_MIXC}};
 
-int main() {
+int main(int argc, char **argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     unsigned long long *cyc;
@@ -175,6 +186,11 @@ int main() {
     for (int w : wps) printf("  %dw/SIMD", w);
     printf("   (cycles per wave-instruction per SIMD, median over waves)\n");
     for (auto &e : ents) {
+        if (argc > 1) {          // only the ops named on the command line
+            bool want = false;
+            for (int k = 1; k < argc; ++k) want = want || !strcmp(argv[k], e.name);
+            if (!want) continue;
+        }
         printf("%-10s", e.name);
         for (int w : wps) {
             const int nwg = w > 4 ? 2 : 1;
