@@ -100,12 +100,16 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
     constexpr int PW = TW + 2 * kHalo, PH = TH + 2 * kHalo;
     static_assert(TW * TH == 4 * NT && PW % 4 == 0, "four adjacent pixels per thread, dword-aligned tile rows");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int s_found;      // list mode: the next marked unit
     const int8_t *s_lut = (const int8_t *)smem;
     uint8_t *s_img = smem + kU1TableBytes;
 
     // list mode: a fixed grid of persistent workgroups; each walks an XCD-contiguous range of tiles (neighbouring tiles
     // share halo lines in one L2) and takes those the tube kernel marked in a.tile_list[tile]
     constexpr bool listed = LIST;
+    // nothing marked (smooth content): leave at once -- a workgroup would otherwise walk its share of the marks one dependent global
+    // load at a time (80 us per 32-frame launch for marks that are all zero)
+    if (listed && a.tile_count && __builtin_amdgcn_readfirstlane((int)*a.tile_count) == 0) return;
     const int nt_all = a.N * a.tiles_x * a.tiles_y;
     const int G = (int)gridDim.x;
     // few marked tiles (fewer than half the workgroups): the unit of work is one CHANNEL of a tile, so that the launch does
@@ -120,7 +124,19 @@ __global__ void __launch_bounds__(NT) stage_u1w_kernel(StageArgs a) {
     for (;; t_cur += t_step) {
     int n, y0, x0, c_lo = 0, c_n = a.C;
     if (listed) {
-        while (t_cur < t_last && a.tile_list[t_cur / nsub] == 0u) t_cur += t_step;       // workgroup-uniform
+        // the next marked unit of this workgroup's run: NT candidates are looked at per round, one per thread (a serial walk is one
+        // dependent global load per unit: 80 us per 32-frame launch when only a few tiles are marked)
+        while (t_cur < t_last) {       // workgroup-uniform
+            __syncthreads();           // the previous round's result has been read
+            if (threadIdx.x == 0) s_found = 0x7fffffff;
+            __syncthreads();
+            const long long cand = (long long)t_cur + (long long)threadIdx.x * t_step;
+            if (cand < t_last && a.tile_list[cand / nsub] != 0u) atomicMin(&s_found, (int)cand);
+            __syncthreads();
+            const int f = s_found;
+            if (f != 0x7fffffff) { t_cur = f; break; }
+            t_cur = (long long)t_cur + (long long)NT * t_step > (long long)t_last ? t_last : t_cur + NT * t_step;
+        }
         if (t_cur >= t_last) break;
         decode_tile(a, t_cur / nsub, n, y0, x0, TW, TH);
         if (nsub > 1) { c_lo = t_cur % nsub; c_n = 1; }
