@@ -304,23 +304,14 @@ __device__ __forceinline__ void u1t_pair(const uint32_t (&win)[5][NW], uint32_t 
         for (int j = 0; j < 5; ++j) {
             // LDS addresses as plain integers (dynamic LDS starts at 0 -- checked at kernel entry): going through the
             // `smem` symbol would cost one v_add of a link-time zero per read
-#if defined(MULUT_VARIANT_k1nolds)      /* timing-only: no table reads (wrong results): what the index math and the dot products cost alone */
-            xa[j] = aa[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4));
-            xb2[j] = ab[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4));
-#else
             xa[j] = lds_u32(aa[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
             xb2[j] = lds_u32(ab[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)));
-#endif
         }
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             typedef short s16x2 __attribute__((ext_vector_type(2)));
             const uint32_t t = halves_lo_hi(xa[j], xb2[j]);     // value of pass A | value of pass B
-#if defined(MULUT_VARIANT_k1pkmad)
-            acc.v = (int)pk_mad(t, bp.w[j], (uint32_t)acc.v);      // packed 16-bit sums of the A / B passes (|sum| <= 16 passes x 2048)
-#else
             acc.v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, bp.w[j]), acc.v, false);
-#endif
         }
     } else {
         uint2 xa[5], xb2[5];
@@ -385,9 +376,6 @@ __device__ __forceinline__ uint32_t u1t_pixel(const StageArgs &a, uint32_t pats_
         }
     }
     if constexpr (U == 1) {
-#if defined(MULUT_VARIANT_k1pkmad)
-        acc.v = ((int)((uint32_t)acc.v << 16) >> 16) + (acc.v >> 16);
-#endif
         if (a.use_fma)       // wave-uniform: fused float epilogue proven exact; v_cvt_pk_u8_f32 rounds to nearest even and saturates
             return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)acc.v, a.inv_d, a.epi_c), 0u, 0u);
         return rhe_clip_u8(acc.v + a.bias_num, a.div);
@@ -508,6 +496,7 @@ __global__ void __launch_bounds__(u1t_threads(U, PATS), u1t_waves(U, PATS)) stag
         }
         for (int i = opaque_tid(); i < kU1tDirtyBytes / 4; i += NT) ((uint32_t *)s_dirty)[i] = 0u;      // (read again only after the tile's barriers)
         constexpr int GR = (TW + 8) / 4;            // 18 four-pixel groups cover image columns x0-4 .. x0+67
+        const bool edge_tile = __builtin_amdgcn_readfirstlane((int)(x0 - 4 < 0 || x0 - 4 + 4 * (GR - 1) > a.W - 4)) != 0;
         // a group of four pixels of one image row, as two packed byte pairs per channel (edge columns replicated)
         auto group_hwc = [&](int row, int g, uint32_t (&bp)[6]) {
             const int gy = imin(imax(y0 + row - kHalo, ylo), yhi);
@@ -517,10 +506,12 @@ __global__ void __launch_bounds__(u1t_threads(U, PATS), u1t_waves(U, PATS)) stag
             bp[0] = __builtin_amdgcn_perm(0u, d0, 0x0C030C00u); bp[1] = __builtin_amdgcn_perm(d2, d1, 0x0C050C02u);
             bp[2] = __builtin_amdgcn_perm(d1, d0, 0x0C040C01u); bp[3] = __builtin_amdgcn_perm(d2, d1, 0x0C060C03u);
             bp[4] = __builtin_amdgcn_perm(d1, d0, 0x0C050C02u); bp[5] = __builtin_amdgcn_perm(0u, d2, 0x0C030C00u);
-            if (gx < 0) {                 // left of the image: every column replicates column 0
-                bp[0] = bp[1] = pk_dup(bp[0] & 0xFFFFu); bp[2] = bp[3] = pk_dup(bp[2] & 0xFFFFu); bp[4] = bp[5] = pk_dup(bp[4] & 0xFFFFu);
-            } else if (gx > a.W - 4) {    // right of it: column W-1
-                bp[0] = bp[1] = pk_dup(bp[1] >> 16); bp[2] = bp[3] = pk_dup(bp[3] >> 16); bp[4] = bp[5] = pk_dup(bp[5] >> 16);
+            if (edge_tile) {              // workgroup-uniform: interior tiles skip the per-lane choice (v_cndmask_b32 issues at a quarter of the rate of the others)
+                if (gx < 0) {                 // left of the image: every column replicates column 0
+                    bp[0] = bp[1] = pk_dup(bp[0] & 0xFFFFu); bp[2] = bp[3] = pk_dup(bp[2] & 0xFFFFu); bp[4] = bp[5] = pk_dup(bp[4] & 0xFFFFu);
+                } else if (gx > a.W - 4) {    // right of it: column W-1
+                    bp[0] = bp[1] = pk_dup(bp[1] >> 16); bp[2] = bp[3] = pk_dup(bp[3] >> 16); bp[4] = bp[5] = pk_dup(bp[5] >> 16);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 6; ++k) bp[k] = codes_of(bp[k]);
@@ -530,8 +521,10 @@ __global__ void __launch_bounds__(u1t_threads(U, PATS), u1t_waves(U, PATS)) stag
             const int gx = x0 - 4 + 4 * g, cgx = imin(imax(gx, 0), a.W - 4);
             const uint32_t d = *(const uint32_t *)view_addr(a.in, n, c, gy, cgx);
             p01 = __builtin_amdgcn_perm(0u, d, 0x0C010C00u); p23 = __builtin_amdgcn_perm(0u, d, 0x0C030C02u);
-            if (gx < 0) p01 = p23 = pk_dup(p01 & 0xFFFFu);
-            else if (gx > a.W - 4) p01 = p23 = pk_dup(p23 >> 16);
+            if (edge_tile) {
+                if (gx < 0) p01 = p23 = pk_dup(p01 & 0xFFFFu);
+                else if (gx > a.W - 4) p01 = p23 = pk_dup(p23 >> 16);
+            }
             p01 = codes_of(p01); p23 = codes_of(p23);
         };
         if (a.verdict_take >= 0 && (hwc3 || planar)) {

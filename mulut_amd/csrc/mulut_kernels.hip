@@ -1030,15 +1030,23 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
         int lane = (int)(threadIdx.x & 63);
         asm volatile("" : "+v"(lane));
         if (dw_ok) {
+            // does the image (columns x0 - 4 .. x0 + 19) reach beyond the frame?  Wave-uniform: the selectors of an interior tile are constants
+            // (chosen per lane they are two v_cndmask_b32 each -- 12.6 cycles per instruction and SIMD, profiles/r01_ubench_valu_issue_cost.txt)
+            const bool edge = __builtin_amdgcn_readfirstlane((int)(x0 - kTubeHaloX < 0 || x0 - kTubeHaloX + 4 * (DW - 1) > a.W - 4)) != 0;
 #pragma unroll
             for (int k = 0; k < PER4; ++k) {
                 const int i = lane + 64 * k;
                 if (i < a.C * PH * DW) {
-                    const int gx = x0 - kTubeHaloX + 4 * (i % DW);
                     // bytes (b0,b1) / (b2,b3) into 16-bit lanes; a dword clamped at an image edge replicates the edge byte
-                    const uint32_t sel_lo = gx < 0 ? 0x0C000C00u : gx > a.W - 4 ? 0x0C030C03u : 0x0C010C00u;
-                    const uint32_t sel_hi = gx < 0 ? 0x0C000C00u : gx > a.W - 4 ? 0x0C030C03u : 0x0C030C02u;
-                    const uint32_t lo = __builtin_amdgcn_perm(0u, v[k], sel_lo), hi = __builtin_amdgcn_perm(0u, v[k], sel_hi);
+                    uint32_t lo, hi;
+                    if (!edge) {
+                        lo = __builtin_amdgcn_perm(0u, v[k], 0x0C010C00u); hi = __builtin_amdgcn_perm(0u, v[k], 0x0C030C02u);
+                    } else {
+                        const int gx = x0 - kTubeHaloX + 4 * (i % DW);
+                        const uint32_t sel_lo = gx < 0 ? 0x0C000C00u : gx > a.W - 4 ? 0x0C030C03u : 0x0C010C00u;
+                        const uint32_t sel_hi = gx < 0 ? 0x0C000C00u : gx > a.W - 4 ? 0x0C030C03u : 0x0C030C02u;
+                        lo = __builtin_amdgcn_perm(0u, v[k], sel_lo); hi = __builtin_amdgcn_perm(0u, v[k], sel_hi);
+                    }
                     // code1 per 16-bit lane: (b << 12) keeps the LSB nibble in bits 12..15, b >> 4 is the MSB nibble
                     uint2 c2;
                     c2.x = pk_mad(lo, pk_dup(0x1000u), pk_shr4(lo));

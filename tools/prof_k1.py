@@ -23,7 +23,7 @@ for _ in range(5):
 dd = e.debug_read(32, True)
 d = dd[16:20]
 tot = sum(d)
-for name, v in zip(("bands + first barrier", "pixel codes + statistic + barrier", "(unused)", "sites + list pass"), d):
+for name, v in zip(("bands + first barrier", "routing statistic", "tile load + barrier", "sites + list pass"), d):
     print("%-36s %.3f" % (name, v / tot))
 life, real, waves = dd[20], dd[21], dd[22]
 clock = life / max(real, 1) * 0.1
