@@ -171,7 +171,8 @@ int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int
  *   bands of all modes resident in LDS; samples with a pass outside the tube are recomputed from the full table through a device
  *   work list), 6 = hybrid: a per-tile statistic sends smooth 64x16 tiles to the tube kernel and detailed ones to the
  *   detailed-tile path.  (2-4: the band / expanded-band kernels of rounds 1-2, retired: MULUT_EINVAL.)
- * "tube_pipelined": 1 (default) = stage_tube2_kernel where the mode list is "sdy" (every LDS read hand-scheduled, the next pass's
+ * "tube_pipelined": 1 (default) = stage_tube2_kernel where the mode list uses all of s, d, y (any order, repeats, up to 8 modes:
+ *   the common "sdy" and e.g. "sdysd"; every LDS read hand-scheduled, the next pass's
  *   rows in flight under the current pass's multiply-adds, one 16x4 tile per wave, no workgroup barrier), 0 = stage_tube_kernel.
  * "detail_kernel": the detailed tiles of the hybrid: 0 (default) = anchor slabs in LDS (samples grouped by anchor MSB on the
  *   device, stage_slab_kernel; taken when the stage input is planar, < 2^28 bytes, <= 3 modes), 1 = full-table gather kernel.

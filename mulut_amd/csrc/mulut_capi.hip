@@ -539,7 +539,8 @@ static int run_stage_one(mulut_ctx *ctx, int stage, const View &in, const View &
         g.tiles_x = (W + gw - 1) / gw;
         g.tiles_y = (oy1 - oy0 + gh - 1) / gh;
         g.verdict_take = 1;
-        HIP_TRY(ctx, launch_stage_up(g, u, mode, st));
+        if (ctx->n_modes > 4) HIP_TRY(ctx, launch_stage_up_wide4(g, st));      // (merged 16-bit fields hold 4 modes at most)
+        else HIP_TRY(ctx, launch_stage_up(g, u, mode, st));
     }
     HIP_TRY(ctx, launch_stage_up_fix(a, mode, ctx->num_cus, st, ctx->fix_variant));
     return MULUT_OK;
@@ -912,7 +913,7 @@ const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     // (as run_stage decides: the pipelined kernel takes every list that uses all of s, d, y, up to kMaxTube2Modes modes, when the float
     // epilogue is exact for the divisor)
     const bool all3 = strchr(ctx->modes, 's') && strchr(ctx->modes, 'd') && strchr(ctx->modes, 'y');
-    const bool t2 = ctx->tube2 && all3 && ctx->n_modes <= kMaxTube2Modes && ctx->f32_ok[1];
+    const bool t2 = ctx->tube2 && all3 && ctx->n_modes <= kMaxTube2Modes && (ctx->n_modes > 4 || ctx->f32_ok[1]);
     if (ctx->scale == 4 && (ctx->n_modes <= 3 || t2) && ctx->final_kernel != 1) {
         if (ctx->final_kernel == 5) return t2 ? "stage_tube2_kernel<rgb> + stage_up_fix2_kernel" : "stage_tube_kernel<rgb> + stage_up_fix2_kernel";
         if (ctx->detail_kernel == 0)

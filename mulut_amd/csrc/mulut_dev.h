@@ -401,6 +401,22 @@ __device__ __forceinline__ void tube_finish_rows(const StageArgs &a, RotAcc<4> &
 }
 
 
+// The same for mode lists of more than four modes: a block value is the sum of two fields of up to 8160 x modes each (17 bits for 8 modes:
+// added in 32 bits, never merged in a field), the numerator K = sum - unbias goes through the float epilogue where it is proven exact for the
+// divisor (use_f32: 1..6 and 8 modes) and the integer one otherwise.
+__device__ __forceinline__ void tube_finish_rows_wide(const StageArgs &a, const RotAcc<4> &acc, uint32_t (&o)[4]) {
+    const int unbias = 128 * kQ * 4 * a.M - a.bias_num;
+    static_for<0, 4>([&](auto SY) {
+        constexpr int sy = SY;
+        const int k0 = (int)(tube_field<4 * sy + 0>(acc.lo02, acc.hi02) + tube_field<12 + sy>(acc.lo13, acc.hi13)) - unbias;
+        const int k1 = (int)(tube_field<4 * sy + 1>(acc.lo02, acc.hi02) + tube_field<8 + sy>(acc.lo13, acc.hi13)) - unbias;
+        const int k2 = (int)(tube_field<4 * sy + 2>(acc.lo02, acc.hi02) + tube_field<4 + sy>(acc.lo13, acc.hi13)) - unbias;
+        const int k3 = (int)(tube_field<4 * sy + 3>(acc.lo02, acc.hi02) + tube_field<0 + sy>(acc.lo13, acc.hi13)) - unbias;
+        if (a.use_f32) o[sy] = rhe_pack4_f32(k0, k1, k2, k3, a.inv_d);      // wave-uniform
+        else o[sy] = rhe_clip_u8(k0, a.div) | (rhe_clip_u8(k1, a.div) << 8) | (rhe_clip_u8(k2, a.div) << 16) | (rhe_clip_u8(k3, a.div) << 24);
+    });
+}
+
 // where a tile's anchor-MSB histogram / list positions live (tile_stat_kernel writes, the detailed-tile path reads)
 __device__ __forceinline__ size_t detail_hist_index(uint32_t tile, uint32_t ntiles, int b) {
     return ((size_t)(b >> 3) * ntiles + tile) * 8 + (size_t)(b & 7);

@@ -131,7 +131,7 @@ hipError_t launch_stage_tube(const StageArgs &a, const BandArgs &b, int out_mode
 const char *stage_tube_name(int out_mode);
 // the same kernel with every LDS read hand-scheduled (rows of the next pass in flight under the current pass's MACs); built for
 // the mode lists stage_tube2_supported() accepts
-constexpr int kMaxTube2Modes = 4;
+constexpr int kMaxTube2Modes = 8;
 bool stage_tube2_supported(const StageArgs &a);
 hipError_t launch_stage_tube2(const StageArgs &a, const BandArgs &b, int out_mode, int num_cus, hipStream_t st);
 // recompute the pixels listed in a.fix_list[0 .. *a.fix_count) from the full tables (u == 4)

@@ -339,8 +339,14 @@ hipError_t launch_stage_up(const StageArgs &a, int u, int out_mode, hipStream_t 
 
 // u == 4 with more than four modes: per-rotation accumulators (the merged ones would overflow their 16-bit fields)
 hipError_t launch_stage_up_wide4(const StageArgs &a, hipStream_t st) {
-    if (a.C > 3 || a.verdict_take >= 0) return hipErrorInvalidValue;
+    if (a.C > 3) return hipErrorInvalidValue;
     const size_t tile_bytes = ((3 * (size_t)(K2_TH + 2 * kHalo) * (K2_TW + 2 * kHalo) + 15) / 16) * 16;
+    if (a.verdict_take >= 0) {      // hybrid launch: the tiles the statistic marked for this kernel (four blocks per 64x16 verdict tile)
+        const long long nbv = 4LL * a.N * a.vt_x * a.vt_y;
+        if (nbv <= 0 || nbv > 0x7fffffffLL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((stage_up_kernel<4, kOutGeneric, K2_TW, K2_TH, true, true>), dim3((unsigned)nbv), dim3(K2_TW * K2_TH), tile_bytes, st, a);
+        return hipGetLastError();
+    }
     const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;
     if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL((stage_up_kernel<4, kOutGeneric, K2_TW, K2_TH, false, true>), dim3((unsigned)nb), dim3(K2_TW * K2_TH), tile_bytes, st, a);
@@ -1162,9 +1168,12 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
             }
             RotAcc<4> acc;
             // the (0,2) fields start at -unbias (the rows are value + 128: unbias = 128 * 16 * 4 M <= 24576) where the epilogue works on K
+            // more than four modes: the numerator does not fit a signed 16-bit field any more (|K| <= 8192 x modes); the pair sums still fit
+            // their unsigned fields (8160 x modes <= 65280 for 8 modes), so such lists start from zero and take the biased-sum epilogue
+            const bool wide = a.M > 4;      // wave-uniform
             auto acc_start = [&]() {
                 acc.clear();
-                if constexpr (OUT != kOutGeneric) {
+                if (OUT != kOutGeneric && !wide) {
                     const uint32_t nb = pk_dup((uint32_t)(65536 - 128 * kQ * 4 * a.M));      // (a.M: the modes of the list, not the patterns)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) acc.lo02[k] = acc.hi02[k] = nb;
@@ -1202,7 +1211,17 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                     cur = nxt;
                     nxt = nn;
                 });
-                if constexpr (OUT != kOutGeneric) {
+                if (OUT != kOutGeneric && wide) {
+                    tube_finish_rows_wide(a, acc, o);
+                    if constexpr (OUT == kOutPackedRGBU4) {
+                        if (c < 2) park()[c * NT] = make_uint4(o[0], o[1], o[2], o[3]);
+                    } else if constexpr (OUT == kOutPlanarU4) {
+                        int n2, y2, x2, lx2, ly2;
+                        site(n2, y2, x2, lx2, ly2);
+#pragma unroll
+                        for (int sy = 0; sy < 4; ++sy) *(uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n2, c, y2 * 4 + sy, x2 * 4)) = o[sy];
+                    }
+                } else if constexpr (OUT != kOutGeneric) {
                     // Epilogue on the numerators themselves: the (0,2) accumulators started at -unbias (mod 2^16), so the sum of the
                     // two fields of a block position IS K = 16 M pred (mod 2^16, |K| < 2^15).  Per byte: one 16-bit-select add, one
                     // sign-extending convert, one multiply by fl(1/d), one v_cvt_pk_u8_f32 (it rounds to nearest even and saturates:
@@ -1297,12 +1316,14 @@ static bool tube2_counts(const StageArgs &a, int (&cnt)[3]) {
     return true;
 }
 // The kernel is built for the pattern set {s, d, y}; any mode list that uses all three runs on it, in any order and with repeats
-// (kMaxTube2Modes in all: the sign-extending epilogue needs |K| <= 8192 x modes to fit 16 bits).  Lists that lack a pattern would
+// (kMaxTube2Modes = 8 in all: a merged rotation pair sums to <= 8160 x modes in its unsigned 16-bit fields).  Lists that lack a pattern would
 // pay for its passes: they stay with stage_tube_kernel.
 bool stage_tube2_supported(const StageArgs &a) {
     int cnt[3];
     // the float epilogue must be exact for the divisor (StageArgs::use_f32, proven at configure time), the bias the numerator bias of a final stage
-    return a.C <= 3 && a.M <= kMaxTube2Modes && tube2_counts(a, cnt) && cnt[0] && cnt[1] && cnt[2] && a.use_f32 &&
+    // (up to four modes: the float epilogue on the signed 16-bit numerators must be exact for the divisor; five to eight: sums in 32 bits, float
+    // or integer epilogue)
+    return a.C <= 3 && a.M <= kMaxTube2Modes && tube2_counts(a, cnt) && cnt[0] && cnt[1] && cnt[2] && (a.M > 4 || a.use_f32) &&
            a.bias_num == 0;
 }
 

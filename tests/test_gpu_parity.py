@@ -488,6 +488,30 @@ def test_long_mode_lists_in_cascades(stages, scale, modes):
     e.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("modes", ["sdysd", "sdysdysd", "yyddsss"])
+def test_five_to_eight_modes_on_the_lds_path(modes):
+    """x4 final stages with five to eight modes run on the pipelined tube kernel (a mode list is a multiset of the patterns s, d, y; the pair sums
+    still fit their unsigned 16-bit fields, block values are added in 32 bits; seven modes take the integer epilogue), their detailed tiles on the per-rotation gather
+    kernel, their flagged samples on the fix-up kernel: extreme tables (every field at its bound) and random ones, smooth + noisy content,
+    every final-stage variant, vs the oracle."""
+    from mulut_amd import MuLUTEngine
+    rng = np.random.default_rng(len(modes))
+    img = np.stack([np.concatenate([natural_image(40, 70, 3, seed=s), rng.integers(0, 256, (40, 66, 3), dtype=np.uint8)], axis=1) for s in (1, 2)])
+    for val in (127, -128, None):
+        luts = {}
+        for m in set(modes):
+            luts["s1_%s" % m] = synthetic_lut(ord(m), 1)
+            luts["s2_%s" % m] = np.full((17 ** 4, 16), val, np.int8) if val is not None else rng.integers(-128, 128, (17 ** 4, 16), dtype=np.int8)
+        e = MuLUTEngine(0).configure(2, modes, 4, 4).set_lut_dict(luts)
+        assert "stage_tube2_kernel" in e.kernel_name(True)
+        want = np.stack([c_oracle.pipeline(luts, 2, modes, 4, im) for im in img])
+        for sel in (0, 5, 1):
+            e.set_tuning("final_stage_kernel", sel)
+            assert np.array_equal(e.pipeline(dev(img)).cpu().numpy(), want), (modes, val, sel)
+        e.close()
+
+
 def _strip_rank(rank, world, port, q):
     """one rank of the config-3 rehearsal: real engine, strips + halo, gather on rank 0 (gloo moves host memory)"""
     import torch.distributed as dist

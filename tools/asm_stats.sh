@@ -15,5 +15,5 @@ for N in $(grep -o "^_Z[A-Za-z0-9_]*$K[A-Za-z0-9_]*:" $S | tr -d ':'); do
   grep -A14 "\.name: *$N\$" $S | grep "private_segment\|vgpr_count\|sgpr_count\|spill_count" | tr -s ' ' | tr '\n' ' '; echo
 done
 [ -z "$first" ] && { echo "no kernel matches $K"; exit 1; }
-awk -v n="$first:" 'index($0,n)==1{p=1} p{print} /s_endpgm/{if(p){exit}}' $S > $D/kernel.s
+awk -v n="$first:" 'index($0,n)==1{p=1} p{print} /^\.Lfunc_end/{if(p){exit}}' $S > $D/kernel.s      # (a kernel may hold several s_endpgm: cut at the function's end label)
 echo "ISA of $first: $(wc -l < $D/kernel.s) lines, scratch ops $(grep -c scratch_ $D/kernel.s), v_readlane/writelane $(grep -c 'v_readlane\|v_writelane' $D/kernel.s)"
