@@ -824,6 +824,7 @@ __global__ void __launch_bounds__(256) stage_up_fix3_kernel(StageArgs a) {
 hipError_t launch_stage_up_fix(const StageArgs &a, int out_mode, int num_cus, hipStream_t st, int variant) {
     if (a.C > 3 || !a.fix_list || !a.fix_count) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(4 * num_cus)), block(256);
+    if (a.M > 4 && variant == 1) variant = 0;      // the one-entry-per-thread kernel merges rotation pairs in 16-bit fields: four modes at most
     if (variant == 0) hipLaunchKernelGGL(stage_up_fix2_kernel, dim3((unsigned)(8 * num_cus)), block, 0, st, a);
     else if (variant == 2) hipLaunchKernelGGL(stage_up_fix3_kernel, dim3((unsigned)(8 * num_cus)), block, 0, st, a);
     else if (out_mode == kOutPlanarU4) hipLaunchKernelGGL((stage_up_fix_kernel<kOutPlanarU4>), grid, block, 0, st, a);
@@ -1211,15 +1212,22 @@ __global__ void __launch_bounds__(KB_TW *KB_TH) __attribute__((amdgpu_waves_per_
                     cur = nxt;
                     nxt = nn;
                 });
-                if (OUT != kOutGeneric && wide) {
+                if (wide) {
                     tube_finish_rows_wide(a, acc, o);
                     if constexpr (OUT == kOutPackedRGBU4) {
                         if (c < 2) park()[c * NT] = make_uint4(o[0], o[1], o[2], o[3]);
-                    } else if constexpr (OUT == kOutPlanarU4) {
+                    } else {
                         int n2, y2, x2, lx2, ly2;
                         site(n2, y2, x2, lx2, ly2);
 #pragma unroll
-                        for (int sy = 0; sy < 4; ++sy) *(uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n2, c, y2 * 4 + sy, x2 * 4)) = o[sy];
+                        for (int sy = 0; sy < 4; ++sy) {
+                            if constexpr (OUT == kOutPlanarU4) {
+                                *(uint32_t *)const_cast<uint8_t *>(view_addr(a.out, n2, c, y2 * 4 + sy, x2 * 4)) = o[sy];
+                            } else {       // any layout: byte by byte (finish_channel's generic form merges the pairs in 16-bit fields: not for these lists)
+#pragma unroll
+                                for (int sx = 0; sx < 4; ++sx) *const_cast<uint8_t *>(view_addr(a.out, n2, c, y2 * 4 + sy, x2 * 4 + sx)) = (uint8_t)(o[sy] >> (8 * sx));
+                            }
+                        }
                     }
                 } else if constexpr (OUT != kOutGeneric) {
                     // Epilogue on the numerators themselves: the (0,2) accumulators started at -unbias (mod 2^16), so the sum of the

@@ -508,7 +508,15 @@ def test_five_to_eight_modes_on_the_lds_path(modes):
         want = np.stack([c_oracle.pipeline(luts, 2, modes, 4, im) for im in img])
         for sel in (0, 5, 1):
             e.set_tuning("final_stage_kernel", sel)
-            assert np.array_equal(e.pipeline(dev(img)).cpu().numpy(), want), (modes, val, sel)
+            for fixk in (0, 1, 2):        # (1 merges rotation pairs in 16-bit fields: the library takes the default kernel for these lists)
+                e.set_tuning("fix_kernel", fixk)
+                assert np.array_equal(e.pipeline(dev(img)).cpu().numpy(), want), (modes, val, sel, fixk)
+            e.set_tuning("fix_kernel", 0)
+            # two channels (the byte-wise output form) and a planar batch (the dword form) of the same images
+            got2 = e.pipeline(dev(np.ascontiguousarray(img[..., :2]))).cpu().numpy()
+            assert np.array_equal(got2, want[..., :2]), (modes, val, sel, "C=2")
+            gotp = e.pipeline(dev(np.ascontiguousarray(img.transpose(0, 3, 1, 2))), layout=0).cpu().numpy()
+            assert np.array_equal(gotp, want.transpose(0, 3, 1, 2)), (modes, val, sel, "planar")
         e.close()
 
 

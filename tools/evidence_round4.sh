@@ -11,7 +11,8 @@ export MULUT_NO_BUILD=1
 DIST=real bash tools/prof_round.sh ${TAG}_real > $O/prof_${TAG}_real.log 2>&1; echo "prof real rc=$?"
 cp profiles/kernel_counters_real.json profiles/hbm_traffic_real.json $O/ 2>/dev/null
 timeout -k 10 300 python tools/prof_k1.py > $O/${TAG}_k1_phases.txt 2>> $O/${TAG}_bench.err; echo "k1 phases rc=$?"
-timeout -k 10 300 python tools/prof_k1.py --fine > $O/${TAG}_k1_phases_fine.txt 2>> $O/${TAG}_bench.err; echo "k1 fine phases rc=$?"
+[ -x build/ubench_stream_k1 ] && timeout -k 10 120 build/ubench_stream_k1 > $O/${TAG}_ubench_stream_k1.txt 2>&1
+[ -x build/ubench_valu ] && timeout -k 10 200 build/ubench_valu > $O/${TAG}_ubench_valu_issue_cost.txt 2>&1
 ( cd /tmp && export TMPDIR=/tmp
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/small_c5 -- python3 $R/bench.py --config 5 --frames 8 --lr-h 270 --lr-w 480 --steps 50 > $O/${TAG}_small_c5.log 2>&1; echo "c5 small rc=$?"
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/small_set5 -- python3 $R/tools/small_call.py --h 128 --w 128 --reps 50 > $O/${TAG}_small_set5.log 2>&1; echo "set5 rc=$?" )
