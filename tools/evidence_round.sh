@@ -45,6 +45,7 @@ timeout -k 10 400 python bench.py --batch rolled --skip-other --skip-strips --cp
     find $O/stats_${TAG}_$d -name '*kernel_stats.csv' -exec cp {} $O/${TAG}_kernel_stats_$d.csv \;
   done )
 timeout -k 10 600 python tools/fuzz_parity.py --cases 1000 --seed 303 > $O/${TAG}_fuzz_parity.jsonl 2>&1; echo "fuzz parity rc=$?"
+timeout -k 10 900 python tools/fuzz_parity.py --cases 3000 --seed 404 >> $O/${TAG}_fuzz_parity.jsonl 2>&1; echo "fuzz parity (3000) rc=$?"
 timeout -k 10 300 python tools/fuzz_finetune.py --cases 150 --seed 303 > $O/${TAG}_fuzz_finetune.jsonl 2>&1; echo "fuzz finetune rc=$?"
 cp profiles/kernel_counters.json profiles/hbm_traffic.json profiles/valu_issue.json profiles/finetune_counters.json $O/ 2>/dev/null
 echo done

@@ -9,7 +9,7 @@
 //     this kernel with every pixel body executed twice (timing-only)                 122.1   => the bodies cost 48.6 of the 73.5
 //     this kernel without the neighbourhood test (timing-only)                        66.8
 // i.e. the stage is bound by the issue of its pixel bodies (26.7 VALU + 4.3 LDS instructions per pass: 96 SIMD cycles per pass in situ,
-// 64-69 as a microbenchmark of the same stream with conflict-free LDS addresses, profiles/r04j_ubench_stream_k1.txt) whatever the waves do
+// 64-69 as a microbenchmark of the same stream with conflict-free LDS addresses, profiles/r04_ubench_stream_k1.txt) whatever the waves do
 // between them: barrier waits are covered by the other workgroup of the CU, and removing them buys nothing.
 // Goes into mulut_k1.hip before stage_u1t_tile(); launcher at the end.
 
