@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r04_ab.sh <tag> <variants> [frames] [extra ab_bench args]
+# usage: tools/gpu_ab.sh <tag> <variants> [frames] [extra ab_bench args]
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out; mkdir -p $O
