@@ -640,3 +640,30 @@ def test_large_strip_and_stage_calls_run_as_sub_launches(eng, shipped_luts):
     for k in range(n2):
         assert torch.equal(got[k], want[k % 3]), k
     assert torch.equal(want, eng.pipeline(base))
+
+
+@pytest.mark.gpu
+def test_large_batch_captures_into_a_graph_after_reserve(eng, shipped_luts):
+    """mulut_reserve sizes every buffer for the sub-launches a batch beyond the 28-bit sample descriptors runs as, so such a call allocates nothing:
+    it can be captured into a hipGraph (an allocation under capture would fail it) and the replay equals the eager result, on detailed content."""
+    from mulut_amd.synth import noise_frames
+    h, w = 1080, 1920
+    n = (1 << 28) // (h * w * 3) + 2          # 45 frames: two final-stage sub-launches
+    base = dev(noise_frames(3, h, w, 3, 9))
+    x = base.repeat((n + 2) // 3, 1, 1, 1)[:n].contiguous()
+    out = torch.empty((n, 4 * h, 4 * w, 3), dtype=torch.uint8, device="cuda")
+    e = eng
+    e.reserve(n, h, w, 3)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        e.pipeline(x[:3], out=out[:3])        # first launches of every kernel outside capture (they raise the kernels' LDS limits)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        e.pipeline(x, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    ref = e.pipeline(base)
+    for k in range(n):
+        assert torch.equal(out[k], ref[k % 3]), k
