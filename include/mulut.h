@@ -149,6 +149,13 @@ int mulut_debug_read(mulut_ctx *ctx, unsigned long long *out, int cap, int reset
  *   out       : device float32 [B][C][H*u][W*u] in 0..255
  * backward: grad_out = dL/d out; accumulates dL/d weights_q into grad_wq[m] (atomic adds; zero them first) and
  * dL/dx into grad_x (zero it first).  u = upscale for the last stage, else 1. */
+/* The module's quantisation of its float parameters and that step's backward (sr/model.py:74-76), for the M tables of a stage
+ * (n floats each) in one launch:
+ *   mulut_ft_quantize          : weights_q[m][i] = clamp(round(weights[m][i] * 127), -127, 127), round = half to even (torch.round)
+ *   mulut_ft_quantize_backward : grad[m][i] = grad[m][i] * inside * 127 in place, inside = round(weights[m][i] * 127) within [-127, 127]
+ *                                (the rounding is a BPDA identity, :59-67; the clamp passes gradient on its closed interval) */
+int mulut_ft_quantize(int device, const float *const *weights, float *const *weights_q, int M, long long n, void *stream);
+int mulut_ft_quantize_backward(int device, const float *const *weights, float *const *grad, int M, long long n, void *stream);
 int mulut_ft_stage_forward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
                            int B, int C, int H, int W, float *out, void *stream);
 int mulut_ft_stage_backward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,

@@ -325,39 +325,39 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
 // address, and an LDS float add (ds_add_f32) occupies the CU's LDS pipeline for 48 cycles per wave instruction whatever its
 // addresses (tools/ubench/ubench_lds_atomic.hip; an integer add or a plain write takes 3.8, read + add + write of a private
 // address 7).  So the table gradient is summed on three levels:
-//   1. a 16-lane group (lane = row element) owns 16 consecutive sites and a PRIVATE 16-entry cache of band rows in LDS, direct
+//   1. a 16-lane group (lane = row element) owns 16 sites (a 4x4 block) and a PRIVATE 16-entry cache of band rows in LDS, direct
 //      mapped by slot mod 16 -- the 16 corners of one MSB cell have 16 different residues (the tube strides are 11, 2, 12, 8
 //      mod 16), so a group whose sites stay inside a cell never evicts.  A hit is read + add + write, no atomic;
 //   2. an evicted entry (the sites moved on to another cell) and, at the end of a mode, every entry goes into the workgroup's LDS
 //      copy of the tube band (1041 x 16 floats) with ds_add_f32;
 //   3. the band is flushed once per workgroup and mode as contiguous memory-side atomics.
 // Passes outside the tube add to global memory directly (16 lanes per row: 64-byte segments).
-// The sites of a group ARE its 16 lanes, so nothing crosses a wave: at the start of a pass a site lane publishes, for each of
-// the five path vertices, (table row | tube slot, weight / q) in its LDS items; the group walks its 16 sites vertex by vertex
-// (the rows themselves -- one coalesced 64-byte read per site -- are requested one vertex ahead), and the dot product g . row
-// -- the input gradient's ingredient -- comes back to the site's lane as a 16-lane DPP sum through the item.  The cache tags live
-// in registers (lane c of the group holds entry c's): a lookup is two compares and a ballot.  No barrier inside a mode.
-// LDS: [ band gradient 1041 x 16 f32 ][ g of the sites, 17 floats each ][ caches: 16 x 16 f32 per group ][ items: 5 per site ]
+// The sites of a group ARE its 16 lanes, so nothing crosses a wave and nothing goes through LDS items: a site lane keeps the five
+// (table row | tube slot, weight / q) of its pass in registers and the group reads them with DPP row broadcasts; the 80 table rows of
+// a pass (one coalesced 64-byte read per site and vertex) are requested before the first is used.  The group then walks its sites
+// ONE SITE AT A TIME, all five vertices together: a site's vertices are corners of one cell, i.e. five DIFFERENT cache entries, so
+// their five tag + entry reads, adds and writes are independent and in flight together (round 3 walked vertex by vertex, one
+// dependent LDS round trip per site and vertex, at 2 waves per SIMD: the kernel waited 60 % of its wave cycles).  The dot products
+// g . row -- the input gradient's ingredient -- are 16-lane DPP sums and stay in the site's lane.  The cache tags sit in LDS next to
+// the entries (one broadcast read each).  No barrier inside a mode.
+// LDS: [ band gradient 1041 x 16 f32 ][ g of the sites, 17 floats each ][ caches: 16 x 16 f32 per group ][ tags: 16 per group ]
 #ifndef MULUT_FT_ABL
-#define MULUT_FT_ABL 0      // timing-only ablations (tools/ab_bench.py variants ftabl1..5): never in the product build
+#define MULUT_FT_ABL 0      // timing-only ablations (tools/ab_bench.py variants ftabl*): never in the product build
 #endif
 constexpr int kFtB4Sites = 512, kFtB4Groups = kFtB4Sites / 16;
-constexpr int kFtB4GxFloats = 1536;      // rows of the input gradient summed in LDS (as in ft_stage_bwd)
-constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Groups * 16 * 16 * 4 + 5 * kFtB4Sites * 8 + kFtB4GxFloats * 4;
+constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Groups * 16 * 16 * 4 + kFtB4Groups * 16 * 4;
 static_assert(kFtB4Lds <= 160 * 1024, "ft_stage_bwd4: LDS");
 
 __device__ __forceinline__ float ft_sum16(float v) {      // sum over the 16 lanes of a DPP row; every lane gets it
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));      // row_ror:8
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));      // row_ror:4
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, false));      // row_ror:2
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false));      // row_ror:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));      // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, true));      // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, true));      // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, true));      // row_ror:1
     return v;
 }
-
-struct FtItem {
-    int key;        // table row | (tube slot + 1) << 17 (slot + 1 == 0: outside the tube); -1: no site
-    float wq;       // weight / q of the vertex; the group overwrites it with g . row for the site's lane
-};
+// lane K of every 16-lane row to all lanes of its row (v_mov_b32_dpp row_newbcast:K)
+template <int K> __device__ __forceinline__ int ft_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xF, 0xF, true); }
+template <int K> __device__ __forceinline__ float ft_bcast(float v) { return __int_as_float(ft_bcast<K>(__float_as_int(v))); }
 
 __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
     constexpr int U = 4, EL = 16, NT = kFtB4Sites, NG = kFtB4Groups;
@@ -365,11 +365,10 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
     float *s_band = (float *)ft_smem;
     float (*s_g)[17] = (float (*)[17])(ft_smem + kTubeSlots * 16 * 4);
     float *s_cache = (float *)(ft_smem + kTubeSlots * 16 * 4 + NT * 17 * 4);
-    FtItem *s_item = (FtItem *)(s_cache + NG * 256);      // [5][NT]
-    float *s_gx = (float *)(s_item + 5 * NT);             // [kFtB4GxFloats]
+    int *s_tag = (int *)(s_cache + NG * 256);             // [NG][16]
     // a group's 16 sites are a 4x4 block of one plane (lane = 4 * row + column): neighbours in both directions share MSB cells, so
     // the group's cache sees fewer cell changes than with 16 sites along a row; lanes beyond the plane shadow its last site
-    const int e = (int)threadIdx.x & 15, grp = (int)threadIdx.x >> 4, first = grp * 16, gshift = (int)threadIdx.x & 48;
+    const int e = (int)threadIdx.x & 15, grp = (int)threadIdx.x >> 4, first = grp * 16;
     const int bw = (a.W + 3) / 4, bh = (a.H + 3) / 4;
     const long long nblock = (long long)a.B * a.C * bh * bw, block = (long long)blockIdx.x * NG + grp;
     const long long blk = block < nblock ? block : nblock - 1;
@@ -380,22 +379,8 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
     const int y = imin(y0, a.H - 1), x = imin(x0, a.W - 1);
     const float *plane = a.x + bc * a.H * a.W;
     float *gplane = a.gx + bc * a.H * a.W;
-    // input gradient rows in LDS (see ft_stage_bwd): the workgroup's blocks are consecutive in block order, i.e. they lie in a few
-    // consecutive block rows of the stacked image (planes one under the other, each padded to 4 bh rows); two more rows on either side
-    const int Hp = 4 * bh;
-    const long long gby0 = (long long)blockIdx.x * NG / bw;
-    const long long gby1 = ((long long)blockIdx.x * NG + NG - 1 < nblock ? (long long)blockIdx.x * NG + NG - 1 : nblock - 1) / bw;
-    const long long gx_r0 = 4 * gby0 - 2;
-    const int gx_rows = (int)(4 * (gby1 - gby0 + 1) + 4);
-    // (measured: in THIS kernel the LDS pipeline is the busy one -- cache traffic, evictions -- and the 48 ds_add_f32 per site cost more
-    // than the memory-side atomics they replace, 2.38 against 2.27 ms; in ft_stage_bwd they halve the kernel.  MULUT_FT_B4_GX_LDS=1 builds
-    // the LDS variant.)
-#ifndef MULUT_FT_B4_GX_LDS
-#define MULUT_FT_B4_GX_LDS 0
-#endif
-    const int gx_n = (MULUT_FT_B4_GX_LDS && (long long)gx_rows * a.W <= kFtB4GxFloats) ? gx_rows * a.W : 0;      // 0: adds go to memory
-    const int gx_off = (int)((bc * Hp - gx_r0) * a.W);        // index of a pixel in s_gx = its index in the plane + this
-    for (int i = threadIdx.x; i < gx_n; i += NT) s_gx[i] = 0.0f;      // (the first barrier of the mode loop comes before any add)
+    // (the input gradient's 36 adds per site into other pixels go to memory: summing them in LDS rows, as ft_stage_bwd does, was
+    // slower here -- 2.38 against 2.27 ms in round 3 --, this kernel's LDS pipeline is the busier resource)
     {
         float pred[EL];
 #if MULUT_FT_ABL == 2
@@ -413,110 +398,103 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
         });
     }
     float *cache = s_cache + grp * 256;      // [16 entries][16 elements]
+    int *tags = s_tag + grp * 16;            // slot held by entry c, -1: none
     float own = 0.0f;
     for (int m = 0; m < a.M; ++m) {
         const float *tab = a.w[m];
         float *gtab = a.gw[m];
         const int di[3] = {a.di[m][0], a.di[m][1], a.di[m][2]}, dj[3] = {a.dj[m][0], a.dj[m][1], a.dj[m][2]};
         for (int i = threadIdx.x; i < kTubeSlots * 16; i += NT) s_band[i] = 0.0f;
-        int tagreg = -1;      // tag of cache entry e of this group
+        tags[e] = -1;
         __syncthreads();      // band zeroed (and, first trip, s_g written) before any group adds into it
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
-            int src[4];
+            // this lane's site, per vertex: byte offset of the table row, tube slot (-1: the pass is outside the tube -- all five or
+            // none) and weight / q; a lane without a site has row 0, weight 0
+            int roff[5], slotv[5], src[4];
+            float wq[5];
             {
                 FtPass p;
                 ft_pass_setup(plane, a.H, a.W, y, x, r, di, dj, p);
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
-                    FtItem it;
-                    it.key = valid ? (p.idx[j] | ((p.in_tube ? p.tslot[j] + 1 : 0) << 17)) : -1;
-                    it.wq = p.wt[j] / (float)kQ;
-                    s_item[j * NT + threadIdx.x] = it;
+                    roff[j] = valid ? p.idx[j] * (EL * 4) : 0;
+                    slotv[j] = valid && p.in_tube ? p.tslot[j] : -1;
+                    wq[j] = valid ? p.wt[j] / (float)kQ : 0.0f;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) src[j] = p.src[j];
             }
-            // (the 16 sites are this group's own lanes: LDS serves a wave's operations in order, the fences only keep the compiler
-            // from moving the accesses across each other)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const int eo = eo_of_elem<U>(r, e);
-#if MULUT_FT_ABL != 1
-            int key[2][16];
-            float wq[2][16], rowv[2][16];
-            auto request = [&](auto J) {      // items of vertex J and their table rows
-                constexpr int jj = J, b = jj & 1;
+            const char *tabe = (const char *)tab;
+            float rowv[16][5];
+            static_for<0, 16>([&](auto K) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const FtItem it = s_item[jj * NT + first + k];
-                    key[b][k] = it.key; wq[b][k] = it.wq;
-#if MULUT_FT_ABL == 5
-                    rowv[b][k] = 1.0f;
-#else
-                    rowv[b][k] = it.key >= 0 ? tab[(long long)(it.key & 0x1FFFF) * EL + e] : 0.0f;
-#endif
-                }
-            };
-            request(std::integral_constant<int, 0>{});
-            static_for<0, 5>([&](auto J) {
-                constexpr int j = J, b = j & 1;
-                if constexpr (j < 4) request(std::integral_constant<int, j + 1>{});
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if (key[b][k] < 0) continue;      // (uniform in the group)
-                    const float gv = s_g[first + k][eo], v = wq[b][k] * gv;
-                    const float d = ft_sum16(gv * rowv[b][k]);
-                    if (e == 0) s_item[j * NT + first + k].wq = d;
-#if MULUT_FT_ABL != 4
-                    const int slot = (key[b][k] >> 17) - 1;
-                    if (slot >= 0) {
-                        const int c = slot & 15;
-                        const bool mine = e == c;
-                        const unsigned long long hits = __ballot(mine && tagreg == slot);
-#if MULUT_FT_ABL == 7
-                        const bool hit = hits != 12345ull;
-#else
-                        const bool hit = ((hits >> gshift) & 0xFFFFull) != 0ull;
-#endif
-                        float *cp = cache + c * 16 + e;
-                        const float old = *cp;
-                        *cp = hit ? old + v : v;
-                        if (!hit) {      // the sites moved on to another cell: the entry's sum goes into the band
-                            const int t = __shfl(tagreg, c, 16);
-#if MULUT_FT_ABL != 6
-                            if (t >= 0) lds_add_f32(&s_band[t * 16 + e], old);
-#endif
-                            if (mine) tagreg = slot;
-                        }
-                    } else if (v != 0.0f) atomicAdd(&gtab[(long long)(key[b][k] & 0x1FFFF) * EL + e], v);
-#endif
-                }
+                for (int j = 0; j < 5; ++j) rowv[K][j] = *(const float *)(tabe + (uint32_t)(ft_bcast<K>(roff[j]) + e * 4));
             });
+            float dm[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};      // g . row of this lane's site, per vertex
+            static_for<0, 16>([&](auto K) {
+                asm volatile("" : : : "memory");      // one site at a time: keeps the scheduler from opening every site's reads and sums at once (registers)
+                const float gv = s_g[first + K][eo];
+                int slot[5];
+                float v[5], d[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    slot[j] = ft_bcast<K>(slotv[j]);
+                    v[j] = ft_bcast<K>(wq[j]) * gv;
+                    d[j] = ft_sum16(gv * rowv[K][j]);
+                }
+                if (e == K) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) dm[j] = d[j];
+                }
+#if MULUT_FT_ABL != 4
+                if (slot[0] >= 0) {      // inside the tube (uniform in the group)
+                    int tg[5];
+                    float old[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        tg[j] = tags[slot[j] & 15];
+                        old[j] = cache[(slot[j] & 15) * 16 + e];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        // hit: old + v; miss: v, and the entry's sum goes into the band
+                        const bool hit = tg[j] == slot[j];
+                        cache[(slot[j] & 15) * 16 + e] = hit ? old[j] + v[j] : v[j];
+                        if (!hit) {
+                            if (tg[j] >= 0) lds_add_f32(&s_band[tg[j] * 16 + e], old[j]);
+                            tags[slot[j] & 15] = slot[j];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        // (the broadcast outside the lane-divergent test below: a DPP read of a lane that is switched off returns 0)
+                        const uint32_t off = (uint32_t)(ft_bcast<K>(roff[j]) + e * 4);
+                        if (v[j] != 0.0f) atomicAdd((float *)((char *)gtab + off), v[j]);
+                    }
+                }
 #endif
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            });
             // d/d f of rank j = (g . p_j - g . p_{j-1}) / q, to the source pixel of that rank
-            float dprev = s_item[threadIdx.x].wq;
+            float dprev = dm[0];
 #pragma unroll
             for (int j = 1; j < 5; ++j) {
-                const float cur = s_item[j * NT + threadIdx.x].wq;
-                const float df = (cur - dprev) / (float)kQ;
+                const float df = (dm[j] - dprev) / (float)kQ;
 #if MULUT_FT_ABL != 3
                 if (src[j - 1] == y * a.W + x) own += df;      // the site's own pixel is a key of every pass: summed here, added once
-                else if (valid && df != 0.0f) {
-                    if (gx_n) lds_add_f32(&s_gx[src[j - 1] + gx_off], df);
-                    else atomicAdd(&gplane[src[j - 1]], df);
-                }
+                else if (valid && df != 0.0f) atomicAdd(&gplane[src[j - 1]], df);
 #else
                 if (valid && df == 123.456f) atomicAdd(&gplane[src[j - 1]], df);
 #endif
-                dprev = cur;
+                dprev = dm[j];
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         // the group's cache into the band, then the band's rows (tube rows of anchor MSB A, 16 lanes per row) into the table gradient
 #pragma unroll 1
         for (int c = 0; c < 16; ++c) {
-            const int t = __shfl(tagreg, c, 16);
+            const int t = tags[c];
             if (t >= 0) lds_add_f32(&s_band[t * 16 + e], cache[c * 16 + e]);
         }
         lds_adds_done();
@@ -531,15 +509,6 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
         __syncthreads();
     }
     if (valid && own != 0.0f) atomicAdd(&gplane[y * a.W + x], own);
-    // (every add into s_gx was drained before the last mode's barrier)
-    for (int i = threadIdx.x; i < gx_n; i += NT) {
-        const float v = s_gx[i];
-        const long long r = gx_r0 + i / a.W;
-        if (v == 0.0f || r < 0) continue;
-        const long long pl = r / Hp;
-        const int yy = (int)(r % Hp);
-        if (pl < (long long)a.B * a.C && yy < a.H) atomicAdd(&a.gx[(pl * a.H + yy) * a.W + i % a.W], v);
-    }
 }
 
 template <int U>
@@ -560,9 +529,45 @@ static hipError_t launch_ft(const FtArgs &a, bool backward, hipStream_t st) {
     return hipGetLastError();
 }
 
+// The module's quantisation step and its backward (sr/model.py:74-76: weight = clamp(round_func(weight * 127), -127, 127), round_func a
+// BPDA identity), for all tables of a stage in one launch: as torch operations they are six launches per table and direction.
+struct FtQuantArgs {
+    const float *w[kMaxFtModes];
+    float *o[kMaxFtModes];
+    long long n;
+};
+template <bool BACKWARD>
+__global__ void __launch_bounds__(256) ft_quantize_kernel(FtQuantArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int m = (int)blockIdx.y;
+    const float r = rintf(a.w[m][i] * 127.0f);          // torch.round: half to even
+    if (BACKWARD) a.o[m][i] = a.o[m][i] * ((r >= -127.0f && r <= 127.0f) ? 1.0f : 0.0f) * 127.0f;      // the clamp passes gradient inside [-127, 127] inclusive
+    else a.o[m][i] = fminf(fmaxf(r, -127.0f), 127.0f);
+}
+
 }  // namespace mulut
 
 using namespace mulut;
+
+static int ft_quantize(int device, const float *const *w, float *const *o, int M, long long n, bool backward, void *stream) {
+    if (!w || !o || n <= 0) return MULUT_EINVAL;
+    if (M < 1 || M > kMaxFtModes) return MULUT_EUNSUPPORTED;
+    FtQuantArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int m = 0; m < M; ++m) {
+        if (!w[m] || !o[m]) return MULUT_EINVAL;
+        a.w[m] = w[m];
+        a.o[m] = o[m];
+    }
+    a.n = n;
+    const long long nb = (n + 255) / 256;
+    if (nb > 0x7fffffffLL) return MULUT_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return MULUT_ENODEVICE;
+    if (backward) hipLaunchKernelGGL(ft_quantize_kernel<true>, dim3((unsigned)nb, (unsigned)M), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ft_quantize_kernel<false>, dim3((unsigned)nb, (unsigned)M), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? MULUT_OK : MULUT_EHIP;
+}
 
 static int ft_fill(FtArgs &a, const float *const *weights, float *const *grad_wq, const char *modes, int is_last, int u,
                    const float *x, int B, int C, int H, int W) {
@@ -587,6 +592,14 @@ static int ft_fill(FtArgs &a, const float *const *weights, float *const *grad_wq
 }
 
 extern "C" {
+
+int mulut_ft_quantize(int device, const float *const *weights, float *const *weights_q, int M, long long n, void *stream) {
+    return ft_quantize(device, weights, weights_q, M, n, false, stream);
+}
+
+int mulut_ft_quantize_backward(int device, const float *const *weights, float *const *grad, int M, long long n, void *stream) {
+    return ft_quantize(device, weights, grad, M, n, true, stream);
+}
 
 int mulut_ft_stage_forward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
                            int B, int C, int H, int W, float *out, void *stream) {

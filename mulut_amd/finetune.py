@@ -28,18 +28,24 @@ class _StageFn(torch.autograd.Function):
     def forward(ctx, x, modes, is_last, u, *weights):
         lib = _native.load()
         x = x.contiguous()
-        # weight = clamp(round_func(weight * 127), -127, 127)       sr/model.py:74-76
-        rq = [torch.round(w.detach() * 127) for w in weights]
-        wq = [torch.clamp(r, -127, 127).contiguous() for r in rq]
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        # weight = clamp(round_func(weight * 127), -127, 127)       sr/model.py:74-76, the stage's tables in one launch
+        ws = [w.detach().contiguous() for w in weights]
+        n = ws[0].numel()
+        if any(w.numel() != n or w.dtype != torch.float32 for w in ws):
+            raise ValueError("the tables of a stage must be float32 of one shape")
+        wq_all = torch.empty((len(ws), n), dtype=torch.float32, device=x.device)
+        wq = [wq_all[m].view(w.shape) for m, w in enumerate(ws)]
+        rc = lib.mulut_ft_quantize(x.device.index, _ptr_array(ws), _ptr_array(wq), len(ws), n, stream)
+        if rc:
+            raise RuntimeError(lib.mulut_strerror(rc).decode())
         B, C, H, W = x.shape
         out = torch.empty((B, C, H * u, W * u), dtype=torch.float32, device=x.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         rc = lib.mulut_ft_stage_forward(x.device.index, _ptr_array(wq), modes.encode(), int(is_last), int(u), x.data_ptr(),
                                         B, C, H, W, out.data_ptr(), stream)
         if rc:
             raise (ValueError if rc == -2 else RuntimeError)(lib.mulut_strerror(rc).decode())
-        ctx.save_for_backward(x, *wq)
-        ctx.inside = [(r >= -127) & (r <= 127) for r in rq]     # where the clamp lets gradient through
+        ctx.save_for_backward(x, wq_all, *ws)
         ctx.cfg = (modes, is_last, u)
         return out
 
@@ -47,19 +53,23 @@ class _StageFn(torch.autograd.Function):
     def backward(ctx, gout):
         lib = _native.load()
         modes, is_last, u = ctx.cfg
-        x, *wq = ctx.saved_tensors
+        x, wq_all, *ws = ctx.saved_tensors
+        wq = [wq_all[m].view(w.shape) for m, w in enumerate(ws)]
         gout = gout.contiguous()
         B, C, H, W = x.shape
-        gwq = [torch.zeros_like(w) for w in wq]
+        g_all = torch.zeros_like(wq_all)
+        gwq = [g_all[m].view(w.shape) for m, w in enumerate(ws)]
         gx = torch.zeros_like(x)
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         rc = lib.mulut_ft_stage_backward(x.device.index, _ptr_array(wq), modes.encode(), int(is_last), int(u), x.data_ptr(),
                                          gout.data_ptr(), B, C, H, W, _ptr_array(gwq), gx.data_ptr(), stream)
         if rc:
             raise RuntimeError(lib.mulut_strerror(rc).decode())
-        # backward of clamp(round_func(w*127)): round is identity (BPDA), clamp passes inside [-127,127], x127
-        grads = [g * inside * 127.0 for g, inside in zip(gwq, ctx.inside)]
-        return (gx, None, None, None) + tuple(grads)
+        # backward of clamp(round_func(w*127)): round is identity (BPDA), clamp passes inside [-127,127], x127 -- in place, one launch
+        rc = lib.mulut_ft_quantize_backward(x.device.index, _ptr_array(ws), _ptr_array(gwq), len(ws), ws[0].numel(), stream)
+        if rc:
+            raise RuntimeError(lib.mulut_strerror(rc).decode())
+        return (gx, None, None, None) + tuple(gwq)
 
 
 class MuLUT(nn.Module):

@@ -32,7 +32,7 @@ def main():
                 src = os.path.join(ROOT, "tests", "golden", "luts", "LUT_ft_x4_4bit_int8_s%d_%s.npy" % (s, m))
                 np.save(os.path.join(td, "LUT_x4_4bit_int8_s%d_%s.npy" % (s, m)), np.load(src))
         net = MuLUT(td, 2, "sdy", upscale=4, interval=4).cuda()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fused=True)       # one launch for the six tables
     g = torch.Generator(device="cuda").manual_seed(0)
     if args.data == "noise":
         x = torch.randint(0, 256, (args.bs, 1, args.crop, args.crop), device="cuda", generator=g).float() / 255.0
