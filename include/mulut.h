@@ -161,6 +161,14 @@ int mulut_ft_stage_forward(int device, const float *const *weights_q, const char
 int mulut_ft_stage_backward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
                             const float *grad_out, int B, int C, int H, int W, float *const *grad_wq, float *grad_x,
                             void *stream);
+/* The same pair with the clamp's mask handed from the forward to the backward: inside[(b*C + c)*H*W + y*W + x] bit sy*u+sx is set where
+ * 0 <= pred/avg + bias <= 255 at that block position (:309, the closed interval on which the clamp passes gradient).  The plain backward
+ * recomputes the stage forward to get it; with the mask it does not (one sixth of the final-stage backward at bs 256 x 48 x 48). */
+int mulut_ft_stage_forward_mask(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                                int B, int C, int H, int W, float *out, unsigned short *inside, void *stream);
+int mulut_ft_stage_backward_mask(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                                 const float *grad_out, const unsigned short *inside, int B, int C, int H, int W,
+                                 float *const *grad_wq, float *grad_x, void *stream);
 
 /* ---- device-side evaluation (not on the inference path) ---------------------------------------------------
  * Y-channel PSNR and SSIM of a super-resolved frame against its ground truth, exactly as the test script scores

@@ -20,7 +20,7 @@ EXPORTS = [
     "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage", "mulut_pipeline",
     "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing", "mulut_last_stage_ms", "mulut_last_kernel_ms",
     "mulut_set_tuning", "mulut_kernel_name", "mulut_ft_stage_forward", "mulut_ft_stage_backward", "mulut_ft_quantize", "mulut_ft_quantize_backward",
-    "mulut_eval_ws_doubles", "mulut_eval_y", "mulut_last_detail_counters", "mulut_debug_read",
+    "mulut_ft_stage_forward_mask", "mulut_ft_stage_backward_mask", "mulut_eval_ws_doubles", "mulut_eval_y", "mulut_last_detail_counters", "mulut_debug_read",
 ]
 
 _libs = {}
@@ -168,6 +168,8 @@ def load(path=None):
     L.mulut_kernel_name.argtypes = [p, i]
     L.mulut_ft_stage_forward.argtypes = [i, p, c_char_p, i, i, p, i, i, i, i, p, p]
     L.mulut_ft_stage_backward.argtypes = [i, p, c_char_p, i, i, p, p, i, i, i, i, p, p, p]
+    L.mulut_ft_stage_forward_mask.argtypes = [i, p, c_char_p, i, i, p, i, i, i, i, p, p, p]
+    L.mulut_ft_stage_backward_mask.argtypes = [i, p, c_char_p, i, i, p, p, p, i, i, i, i, p, p, p]
     L.mulut_kernel_name.restype = c_char_p
     L.mulut_ft_quantize.argtypes = [i, p, p, i, ctypes.c_longlong, p]
     L.mulut_ft_quantize_backward.argtypes = [i, p, p, i, ctypes.c_longlong, p]
@@ -179,7 +181,7 @@ def load(path=None):
     for name in ("mulut_create", "mulut_destroy", "mulut_configure", "mulut_set_lut", "mulut_pass", "mulut_stage",
                  "mulut_pipeline", "mulut_pipeline_rows", "mulut_halo", "mulut_reserve", "mulut_set_stage_timing",
                  "mulut_last_stage_ms", "mulut_last_kernel_ms", "mulut_set_tuning", "mulut_ft_stage_forward", "mulut_ft_stage_backward",
-                 "mulut_ft_quantize", "mulut_ft_quantize_backward"):
+                 "mulut_ft_quantize", "mulut_ft_quantize_backward", "mulut_ft_stage_forward_mask", "mulut_ft_stage_backward_mask"):
         getattr(L, name).restype = i
     _libs[path] = L
     return L

@@ -26,6 +26,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MULUT_FT_ABL
+#define MULUT_FT_ABL 0      // timing-only ablations (tools/ab_bench.py variants ftabl*): never in the product build
+#endif
+
 namespace mulut {
 
 constexpr int kMaxFtModes = MULUT_MAX_MODES;
@@ -37,6 +41,8 @@ struct FtArgs {
     const float *gout;  // [B][C][H*u][W*u]
     float *out;         // [B][C][H*u][W*u]
     float *gx;          // [B][C][H][W]
+    uint16_t *inside;   // optional [B][C][H][W]: bit eo of a site = the stage's clamp lets gradient through at block position eo
+                        // (0 <= pred / avg + bias <= 255); the forward writes it, a backward that gets it skips the forward recomputation
     int B, C, H, W, u, M, is_last;
     int di[kMaxFtModes][3], dj[kMaxFtModes][3];
 };
@@ -162,11 +168,44 @@ __global__ void __launch_bounds__(256) ft_stage_fwd(FtArgs a) {
     ft_site_forward<U>(a, plane, y, x, pred);
     const float avg = a.is_last ? (float)a.M : (float)(4 * a.M), bias = a.is_last ? 0.0f : 127.0f;
     float *po = a.out + bc * (long long)(a.H * U) * (a.W * U);
+    uint32_t inside = 0;
     static_for<0, U * U>([&](auto E) {
         constexpr int eo = E;
-        const float t = fminf(fmaxf(pred[eo] / avg + bias, 0.0f), 255.0f);
+        const float t0 = pred[eo] / avg + bias;
+        inside |= (t0 >= 0.0f && t0 <= 255.0f) ? 1u << eo : 0u;
+        const float t = fminf(fmaxf(t0, 0.0f), 255.0f);
         po[(long long)(y * U + eo / U) * (a.W * U) + (x * U + eo % U)] = rintf(t);
     });
+    if (a.inside) a.inside[s] = (uint16_t)inside;
+}
+
+// g = dL/d pred of one site: the clamp's mask (saved by the forward, or from the stage forward recomputed here), then d(pred / avg)
+template <int U, class F>
+__device__ __forceinline__ void ft_site_g(const FtArgs &a, const float *plane, long long bc, int y, int x, bool valid, F &&put) {
+    constexpr int EL = U * U;
+    const float avg = a.is_last ? (float)a.M : (float)(4 * a.M), bias = a.is_last ? 0.0f : 127.0f;
+    const float *pg = a.gout + bc * (long long)(a.H * U) * (a.W * U);
+    if (a.inside) {
+        const uint32_t inside = valid ? a.inside[(bc * a.H + y) * a.W + x] : 0u;
+        static_for<0, EL>([&](auto E) {
+            constexpr int eo = E;
+            const float go = pg[(long long)(y * U + eo / U) * (a.W * U) + (x * U + eo % U)];
+            put(eo, ((inside >> eo) & 1u) ? go / avg : 0.0f);
+        });
+    } else {
+        float pred[EL];
+#if MULUT_FT_ABL == 2
+        for (int q = 0; q < EL; ++q) pred[q] = 100.0f;
+#else
+        ft_site_forward<U>(a, plane, y, x, pred);
+#endif
+        static_for<0, EL>([&](auto E) {
+            constexpr int eo = E;
+            const float t = pred[eo] / avg + bias;
+            const float go = pg[(long long)(y * U + eo / U) * (a.W * U) + (x * U + eo % U)];
+            put(eo, (valid && t >= 0.0f && t <= 255.0f) ? go / avg : 0.0f);
+        });
+    }
 }
 
 // float add into LDS as ds_add_f32: an atomicAdd on a pointer the compiler cannot prove to be LDS (here: one of two targets chosen
@@ -222,19 +261,10 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
     if constexpr (U == 1)
         for (int i = threadIdx.x; i < a.M * kTubeSlots; i += NT) s_band[i] = 0.0f;
     float g[EL];
-    {
-        float pred[EL];
-        ft_site_forward<U>(a, plane, y, x, pred);
-        const float avg = a.is_last ? (float)a.M : (float)(4 * a.M), bias = a.is_last ? 0.0f : 127.0f;
-        const float *pg = a.gout + bc * (long long)(a.H * U) * (a.W * U);
-        static_for<0, EL>([&](auto E) {
-            constexpr int eo = E;
-            const float t = pred[eo] / avg + bias;
-            const float go = pg[(long long)(y * U + eo / U) * (a.W * U) + (x * U + eo % U)];
-            g[eo] = (valid && t >= 0.0f && t <= 255.0f) ? go / avg : 0.0f;   // clamp backward, then d(pred/avg)
-            s_g[threadIdx.x][eo] = g[eo];
-        });
-    }
+    ft_site_g<U>(a, plane, bc, y, x, valid, [&](int eo, float v) {
+        g[eo] = v;
+        s_g[threadIdx.x][eo] = v;
+    });
     __syncthreads();      // the band and the gradient rows must be zero before any wave adds into them
     float own = 0.0f;
     for (int m = 0; m < a.M; ++m) {
@@ -341,9 +371,6 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
 // g . row -- the input gradient's ingredient -- are 16-lane DPP sums and stay in the site's lane.  The cache tags sit in LDS next to
 // the entries (one broadcast read each).  No barrier inside a mode.
 // LDS: [ band gradient 1041 x 16 f32 ][ g of the sites, 17 floats each ][ caches: 16 x 16 f32 per group ][ tags: 16 per group ]
-#ifndef MULUT_FT_ABL
-#define MULUT_FT_ABL 0      // timing-only ablations (tools/ab_bench.py variants ftabl*): never in the product build
-#endif
 constexpr int kFtB4Sites = 512, kFtB4Groups = kFtB4Sites / 16;
 constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Groups * 16 * 16 * 4 + kFtB4Groups * 16 * 4;
 static_assert(kFtB4Lds <= 160 * 1024, "ft_stage_bwd4: LDS");
@@ -381,22 +408,7 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
     float *gplane = a.gx + bc * a.H * a.W;
     // (the input gradient's 36 adds per site into other pixels go to memory: summing them in LDS rows, as ft_stage_bwd does, was
     // slower here -- 2.38 against 2.27 ms in round 3 --, this kernel's LDS pipeline is the busier resource)
-    {
-        float pred[EL];
-#if MULUT_FT_ABL == 2
-        for (int q = 0; q < EL; ++q) pred[q] = 100.0f;
-#else
-        ft_site_forward<U>(a, plane, y, x, pred);
-#endif
-        const float avg = a.is_last ? (float)a.M : (float)(4 * a.M), bias = a.is_last ? 0.0f : 127.0f;
-        const float *pg = a.gout + bc * (long long)(a.H * U) * (a.W * U);
-        static_for<0, EL>([&](auto E) {
-            constexpr int eo = E;
-            const float t = pred[eo] / avg + bias;
-            const float go = pg[(long long)(y * U + eo / U) * (a.W * U) + (x * U + eo % U)];
-            s_g[threadIdx.x][eo] = (valid && t >= 0.0f && t <= 255.0f) ? go / avg : 0.0f;
-        });
-    }
+    ft_site_g<U>(a, plane, bc, y, x, valid, [&](int eo, float v) { s_g[threadIdx.x][eo] = v; });
     float *cache = s_cache + grp * 256;      // [16 entries][16 elements]
     int *tags = s_tag + grp * 16;            // slot held by entry c, -1: none
     float own = 0.0f;
@@ -601,32 +613,58 @@ int mulut_ft_quantize_backward(int device, const float *const *weights, float *c
     return ft_quantize(device, weights, grad, M, n, true, stream);
 }
 
-int mulut_ft_stage_forward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
-                           int B, int C, int H, int W, float *out, void *stream) {
+static int ft_forward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                      int B, int C, int H, int W, float *out, uint16_t *inside, void *stream) {
     FtArgs a;
     int rc = ft_fill(a, weights_q, nullptr, modes, is_last, u, x, B, C, H, W);
     if (rc) return rc;
     if (!out) return MULUT_EINVAL;
     a.out = out;
+    a.inside = inside;
     if (hipSetDevice(device) != hipSuccess) return MULUT_ENODEVICE;
     hipError_t e = u == 1 ? launch_ft<1>(a, false, (hipStream_t)stream) : u == 2 ? launch_ft<2>(a, false, (hipStream_t)stream)
                  : u == 3 ? launch_ft<3>(a, false, (hipStream_t)stream) : launch_ft<4>(a, false, (hipStream_t)stream);
     return e == hipSuccess ? MULUT_OK : MULUT_EHIP;
 }
 
-int mulut_ft_stage_backward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
-                            const float *grad_out, int B, int C, int H, int W, float *const *grad_wq, float *grad_x,
-                            void *stream) {
+int mulut_ft_stage_forward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                           int B, int C, int H, int W, float *out, void *stream) {
+    return ft_forward(device, weights_q, modes, is_last, u, x, B, C, H, W, out, nullptr, stream);
+}
+
+int mulut_ft_stage_forward_mask(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                                int B, int C, int H, int W, float *out, unsigned short *inside, void *stream) {
+    if (!inside) return MULUT_EINVAL;
+    return ft_forward(device, weights_q, modes, is_last, u, x, B, C, H, W, out, inside, stream);
+}
+
+static int ft_backward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                       const float *grad_out, const uint16_t *inside, int B, int C, int H, int W, float *const *grad_wq, float *grad_x,
+                       void *stream) {
     FtArgs a;
     int rc = ft_fill(a, weights_q, grad_wq, modes, is_last, u, x, B, C, H, W);
     if (rc) return rc;
     if (!grad_out || !grad_wq || !grad_x) return MULUT_EINVAL;
     a.gout = grad_out;
     a.gx = grad_x;
+    a.inside = const_cast<uint16_t *>(inside);
     if (hipSetDevice(device) != hipSuccess) return MULUT_ENODEVICE;
     hipError_t e = u == 1 ? launch_ft<1>(a, true, (hipStream_t)stream) : u == 2 ? launch_ft<2>(a, true, (hipStream_t)stream)
                  : u == 3 ? launch_ft<3>(a, true, (hipStream_t)stream) : launch_ft<4>(a, true, (hipStream_t)stream);
     return e == hipSuccess ? MULUT_OK : MULUT_EHIP;
+}
+
+int mulut_ft_stage_backward(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                            const float *grad_out, int B, int C, int H, int W, float *const *grad_wq, float *grad_x,
+                            void *stream) {
+    return ft_backward(device, weights_q, modes, is_last, u, x, grad_out, nullptr, B, C, H, W, grad_wq, grad_x, stream);
+}
+
+int mulut_ft_stage_backward_mask(int device, const float *const *weights_q, const char *modes, int is_last, int u, const float *x,
+                                 const float *grad_out, const unsigned short *inside, int B, int C, int H, int W,
+                                 float *const *grad_wq, float *grad_x, void *stream) {
+    if (!inside) return MULUT_EINVAL;
+    return ft_backward(device, weights_q, modes, is_last, u, x, grad_out, inside, B, C, H, W, grad_wq, grad_x, stream);
 }
 
 }  // extern "C"

@@ -41,11 +41,13 @@ class _StageFn(torch.autograd.Function):
             raise RuntimeError(lib.mulut_strerror(rc).decode())
         B, C, H, W = x.shape
         out = torch.empty((B, C, H * u, W * u), dtype=torch.float32, device=x.device)
-        rc = lib.mulut_ft_stage_forward(x.device.index, _ptr_array(wq), modes.encode(), int(is_last), int(u), x.data_ptr(),
-                                        B, C, H, W, out.data_ptr(), stream)
+        # where the stage's clamp passes gradient, 16 bits per site: saves the backward a recomputation of the stage forward
+        inside = torch.empty((B, C, H, W), dtype=torch.int16, device=x.device)
+        rc = lib.mulut_ft_stage_forward_mask(x.device.index, _ptr_array(wq), modes.encode(), int(is_last), int(u), x.data_ptr(),
+                                             B, C, H, W, out.data_ptr(), inside.data_ptr(), stream)
         if rc:
             raise (ValueError if rc == -2 else RuntimeError)(lib.mulut_strerror(rc).decode())
-        ctx.save_for_backward(x, wq_all, *ws)
+        ctx.save_for_backward(x, wq_all, inside, *ws)
         ctx.cfg = (modes, is_last, u)
         return out
 
@@ -53,7 +55,7 @@ class _StageFn(torch.autograd.Function):
     def backward(ctx, gout):
         lib = _native.load()
         modes, is_last, u = ctx.cfg
-        x, wq_all, *ws = ctx.saved_tensors
+        x, wq_all, inside, *ws = ctx.saved_tensors
         wq = [wq_all[m].view(w.shape) for m, w in enumerate(ws)]
         gout = gout.contiguous()
         B, C, H, W = x.shape
@@ -61,8 +63,8 @@ class _StageFn(torch.autograd.Function):
         gwq = [g_all[m].view(w.shape) for m, w in enumerate(ws)]
         gx = torch.zeros_like(x)
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        rc = lib.mulut_ft_stage_backward(x.device.index, _ptr_array(wq), modes.encode(), int(is_last), int(u), x.data_ptr(),
-                                         gout.data_ptr(), B, C, H, W, _ptr_array(gwq), gx.data_ptr(), stream)
+        rc = lib.mulut_ft_stage_backward_mask(x.device.index, _ptr_array(wq), modes.encode(), int(is_last), int(u), x.data_ptr(),
+                                              gout.data_ptr(), inside.data_ptr(), B, C, H, W, _ptr_array(gwq), gx.data_ptr(), stream)
         if rc:
             raise RuntimeError(lib.mulut_strerror(rc).decode())
         # backward of clamp(round_func(w*127)): round is identity (BPDA), clamp passes inside [-127,127], x127 -- in place, one launch

@@ -166,3 +166,46 @@ def test_more_shapes_vs_cpu_oracle(tmp_path, stages, modes, scale, shape, kind):
     close(xg.grad.cpu().numpy(), xc.grad.numpy(), "gx")
     for k, w in wcpu.items():
         close(getattr(net, "weight_" + k).grad.cpu().numpy(), w.grad.numpy(), k)
+
+
+@pytest.mark.parametrize("u,is_last,modes,shape", [(4, 1, "sdy", (3, 1, 13, 10)), (1, 0, "sdy", (2, 2, 9, 11)), (2, 1, "sd", (1, 1, 8, 8)), (3, 1, "y", (1, 1, 6, 5))])
+def test_backward_with_the_saved_clamp_mask_equals_the_recomputing_one(u, is_last, modes, shape):
+    """The two forms of the stage ABI: mulut_ft_stage_forward/backward (the backward recomputes the stage forward for the clamp mask)
+    and the _mask pair (the forward hands the mask over).  Tables with large entries so that the clamp bites on both sides."""
+    import ctypes
+    from mulut_amd import _native
+    lib = _native.load()
+    rng = np.random.default_rng(100 * u + len(modes))
+    B, C, H, W = shape
+    M = len(modes)
+    wq = [torch.from_numpy(np.clip(rng.normal(0, 90, (17 ** 4, u * u)).round(), -127, 127).astype(np.float32)).cuda() for _ in modes]
+    x = torch.from_numpy(rng.integers(0, 256, shape).astype(np.float32)).cuda()
+    gout = torch.from_numpy(rng.standard_normal((B, C, H * u, W * u)).astype(np.float32)).cuda()
+    ptrs = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])      # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out0, out1 = torch.empty_like(gout), torch.empty_like(gout)
+    inside = torch.zeros(shape, dtype=torch.int16, device="cuda")
+    assert lib.mulut_ft_stage_forward(0, ptrs(wq), modes.encode(), is_last, u, x.data_ptr(), B, C, H, W, out0.data_ptr(), st) == 0
+    assert lib.mulut_ft_stage_forward_mask(0, ptrs(wq), modes.encode(), is_last, u, x.data_ptr(), B, C, H, W, out1.data_ptr(), inside.data_ptr(), st) == 0
+    assert torch.equal(out0, out1)
+    bits = inside.cpu().numpy().astype(np.uint16)
+    clamped = 1.0 - np.mean([(bits >> e) & 1 for e in range(u * u)])
+    if is_last:
+        assert 0.02 < clamped < 0.98, clamped    # the case exercises both sides of the mask
+    else:
+        assert clamped == 0.0                    # (a non-final stage cannot leave [0, 255]: |pred / 4M| <= 127, bias 127)
+    res = []
+    for masked in (False, True):
+        gw = [torch.zeros_like(w) for w in wq]
+        gx = torch.zeros_like(x)
+        if masked:
+            rc = lib.mulut_ft_stage_backward_mask(0, ptrs(wq), modes.encode(), is_last, u, x.data_ptr(), gout.data_ptr(), inside.data_ptr(),
+                                                  B, C, H, W, ptrs(gw), gx.data_ptr(), st)
+        else:
+            rc = lib.mulut_ft_stage_backward(0, ptrs(wq), modes.encode(), is_last, u, x.data_ptr(), gout.data_ptr(), B, C, H, W, ptrs(gw), gx.data_ptr(), st)
+        assert rc == 0
+        res.append([g.cpu().numpy() for g in gw] + [gx.cpu().numpy()])
+    for g0, g1 in zip(*res):
+        scale = max(float(np.abs(g0).max()), 1e-30)
+        assert scale > 1e-6 and float(np.abs(g0 - g1).max()) <= 2e-5 * scale
+    assert lib.mulut_ft_stage_forward_mask(0, ptrs(wq), modes.encode(), is_last, u, x.data_ptr(), B, C, H, W, out1.data_ptr(), None, st) == -1
