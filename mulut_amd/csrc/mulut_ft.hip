@@ -68,6 +68,7 @@ struct FtPass {
     int src[4];      // flat pixel index (within the channel plane) of the key of rank j
     int tslot[5];    // tube-band slots of the five vertices (mulut_core.h), valid when in_tube
     bool in_tube;    // the four MSBs span at most one step: every vertex lies in the 1041-slot tube band
+    int ord;         // key (0 = a ... 3 = d) of rank j in bits 2j, 2j + 1
 };
 
 __device__ __forceinline__ void ft_pass_setup(const float *plane, int H, int W, int y, int x, int r, const int (&di)[3],
@@ -92,6 +93,7 @@ __device__ __forceinline__ void ft_pass_setup(const float *plane, int H, int W, 
     }
     int o[4];
     ft_order(f[0], f[1], f[2], f[3], o);
+    p.ord = o[0] | (o[1] << 2) | (o[2] << 4) | (o[3] << 6);
     const int stride[4] = {kStrideA, kStrideB, kStrideC, kStrideD};
     float fs[4];
     int ss[4];
@@ -370,9 +372,15 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
 // dependent LDS round trip per site and vertex, at 2 waves per SIMD: the kernel waited 60 % of its wave cycles).  The dot products
 // g . row -- the input gradient's ingredient -- are 16-lane DPP sums and stay in the site's lane.  The cache tags sit in LDS next to
 // the entries (one broadcast read each).  No barrier inside a mode.
+// The INPUT gradient: a pass gives d/d f of each key to that key's pixel.  The site's own pixel (key a) is summed in a register; for
+// key b, c or d the target is the site's pixel plus an offset that is the same for every site of the pass, so the 16 sites of a
+// group hit 16 DIFFERENT positions of the group's 8 x 8 tile (its 4 x 4 block and a halo of two, unclamped): a plain LDS read + add
+// + write per key, no atomic.  The tile goes to memory once, at the end, folded onto the image (replicate padding: a position
+// outside the plane belongs to the border pixel) -- 4 memory-side atomics per site instead of 37.
 // LDS: [ band gradient 1041 x 16 f32 ][ g of the sites, 17 floats each ][ caches: 16 x 16 f32 per group ][ tags: 16 per group ]
+//      [ input-gradient tiles: 8 x 8 f32 per group ]
 constexpr int kFtB4Sites = 512, kFtB4Groups = kFtB4Sites / 16;
-constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Groups * 16 * 16 * 4 + kFtB4Groups * 16 * 4;
+constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Groups * 16 * 16 * 4 + kFtB4Groups * 16 * 4 + kFtB4Groups * 64 * 4;
 static_assert(kFtB4Lds <= 160 * 1024, "ft_stage_bwd4: LDS");
 
 __device__ __forceinline__ float ft_sum16(float v) {      // sum over the 16 lanes of a DPP row; every lane gets it
@@ -393,6 +401,7 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
     float (*s_g)[17] = (float (*)[17])(ft_smem + kTubeSlots * 16 * 4);
     float *s_cache = (float *)(ft_smem + kTubeSlots * 16 * 4 + NT * 17 * 4);
     int *s_tag = (int *)(s_cache + NG * 256);             // [NG][16]
+    float *s_gxt = (float *)(s_tag + NG * 16);            // [NG][8][8]
     // a group's 16 sites are a 4x4 block of one plane (lane = 4 * row + column): neighbours in both directions share MSB cells, so
     // the group's cache sees fewer cell changes than with 16 sites along a row; lanes beyond the plane shadow its last site
     const int e = (int)threadIdx.x & 15, grp = (int)threadIdx.x >> 4, first = grp * 16;
@@ -406,8 +415,10 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
     const int y = imin(y0, a.H - 1), x = imin(x0, a.W - 1);
     const float *plane = a.x + bc * a.H * a.W;
     float *gplane = a.gx + bc * a.H * a.W;
-    // (the input gradient's 36 adds per site into other pixels go to memory: summing them in LDS rows, as ft_stage_bwd does, was
-    // slower here -- 2.38 against 2.27 ms in round 3 --, this kernel's LDS pipeline is the busier resource)
+    float *gxt = s_gxt + grp * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gxt[e + 16 * i] = 0.0f;      // (only this group touches its tile, and LDS serves a wave in order)
+    float *gxt_own = gxt + (2 + (e >> 2)) * 8 + 2 + (e & 3);
     ft_site_g<U>(a, plane, bc, y, x, valid, [&](int eo, float v) { s_g[threadIdx.x][eo] = v; });
     float *cache = s_cache + grp * 256;      // [16 entries][16 elements]
     int *tags = s_tag + grp * 16;            // slot held by entry c, -1: none
@@ -423,7 +434,7 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
         for (int r = 0; r < 4; ++r) {
             // this lane's site, per vertex: byte offset of the table row, tube slot (-1: the pass is outside the tube -- all five or
             // none) and weight / q; a lane without a site has row 0, weight 0
-            int roff[5], slotv[5], src[4];
+            int roff[5], slotv[5], ord;
             float wq[5];
             {
                 FtPass p;
@@ -434,8 +445,7 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
                     slotv[j] = valid && p.in_tube ? p.tslot[j] : -1;
                     wq[j] = valid ? p.wt[j] / (float)kQ : 0.0f;
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) src[j] = p.src[j];
+                ord = p.ord;
             }
             const int eo = eo_of_elem<U>(r, e);
             const char *tabe = (const char *)tab;
@@ -489,18 +499,23 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
                 }
 #endif
             });
-            // d/d f of rank j = (g . p_j - g . p_{j-1}) / q, to the source pixel of that rank
-            float dprev = dm[0];
+            // d/d f of rank j = (g . p_{j+1} - g . p_j) / q belongs to the key of that rank
+            float df[4];
 #pragma unroll
-            for (int j = 1; j < 5; ++j) {
-                const float df = (dm[j] - dprev) / (float)kQ;
+            for (int j = 0; j < 4; ++j) df[j] = (dm[j + 1] - dm[j]) / (float)kQ;
+            const int o0 = ord & 3, o1 = (ord >> 2) & 3, o2 = (ord >> 4) & 3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dk = o0 == k ? df[0] : o1 == k ? df[1] : o2 == k ? df[2] : df[3];
+                if (k == 0) own += dk;
 #if MULUT_FT_ABL != 3
-                if (src[j - 1] == y * a.W + x) own += df;      // the site's own pixel is a key of every pass: summed here, added once
-                else if (valid && df != 0.0f) atomicAdd(&gplane[src[j - 1]], df);
-#else
-                if (valid && df == 123.456f) atomicAdd(&gplane[src[j - 1]], df);
+                else {
+                    int dy, dx;
+                    sample_offset(r, di[k - 1], dj[k - 1], dy, dx);
+                    float *t = gxt_own + dy * 8 + dx;
+                    *t = *t + dk;
+                }
 #endif
-                dprev = dm[j];
             }
         }
         // the group's cache into the band, then the band's rows (tube rows of anchor MSB A, 16 lanes per row) into the table gradient
@@ -520,7 +535,17 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
             }
         __syncthreads();
     }
-    if (valid && own != 0.0f) atomicAdd(&gplane[y * a.W + x], own);
+    // the tile onto the image: position (ty, tx) is pixel (4 by - 2 + ty, 4 bx - 2 + tx) clamped into the plane
+    *gxt_own += valid ? own : 0.0f;
+    if (block < nblock) {
+        const int ty0 = (brem / bw) * 4 - 2, tx0 = (brem % bw) * 4 - 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = e + 16 * i;
+            const float v = gxt[q];
+            if (v != 0.0f) atomicAdd(&gplane[imin(imax(ty0 + (q >> 3), 0), a.H - 1) * a.W + imin(imax(tx0 + (q & 7), 0), a.W - 1)], v);
+        }
+    }
 }
 
 template <int U>
