@@ -61,6 +61,7 @@ struct mulut_ctx {
     int detail_kernel = 0;         // tuning "detail_kernel": 0 = anchor slabs in LDS (when the launch qualifies), 1 = full-table gather kernel
     int first_kernel = 0;   // 1-byte-row stages: 0 auto (tube kernel, detailed tiles to the window kernel), 2 window kernel (full table in
                             // LDS) on every tile, 3 tube kernel on every tile
+    int up_detail_per_1024 = 8;    // the same threshold for the routed x2 / x3 final stages (their detailed tiles go to the gather kernel; profiles/r04y_scale_bench.jsonl)
     int u1_detail_per_1024 = 24;   // a tile goes to the full-table kernel when more than this share of its (sampled) 4-pixel groups spans > 1 MSB step
     uint32_t *tlist = nullptr;     // [16 + tile] = 1: the tube kernel left this tile to the full-table kernel
     size_t tlist_cap = 0;
@@ -259,6 +260,29 @@ int mulut_set_lut(mulut_ctx *ctx, int stage, char mode, const int8_t *host_rows,
                         const uint8_t *e = &img[((size_t)A * kStrideA + B * kStrideB + C * kStrideC + D) * 4];
                         tb[(size_t)tube_slot(A, B, C, D) * 2] = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
                         tb[(size_t)tube_slot(A, B, C, D) * 2 + 1] = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+                    }
+        if (t.tube && t.tube_bytes != tb.size() * 4) {
+            HIP_TRY(ctx, hipFree(t.tube));
+            t.tube = nullptr;
+        }
+        if (!t.tube) HIP_TRY(ctx, hipMalloc(&t.tube, tb.size() * 4));
+        t.tube_bytes = tb.size() * 4;
+        HIP_TRY(ctx, hipMemcpy(t.tube, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
+    } else if (u == 3) {
+        // tube band of a u == 3 table: 24 bytes per slot, the nine values (+ 128) as ten 16-bit fields e0 e1 e2 e3 e4 e4 e5 e6 e7 e8
+        std::vector<uint32_t> tb((size_t)kTube3BandBytes / 4, 0x00800080u);
+        const int rb = row_dwords(3) * 4;
+        for (int A = 0; A < kL; ++A)
+            for (int B = imax(0, A - 2); B <= imin(kL - 1, A + 2); ++B)
+                for (int C = imax(0, A - 2); C <= imin(kL - 1, A + 2); ++C)
+                    for (int D = imax(0, A - 2); D <= imin(kL - 1, A + 2); ++D) {
+                        if (!tube_contains(A, B, C, D)) continue;
+                        const uint8_t *e = &img[((size_t)A * kStrideA + B * kStrideB + C * kStrideC + D) * rb];
+                        uint32_t *d = &tb[(size_t)tube_slot(A, B, C, D) * (kTube3SlotBytes / 4)];
+                        uint32_t f[10];
+                        for (int q = 0; q < 9; ++q) f[tube3_field(q)] = e[q];
+                        f[5] = e[4];
+                        for (int k = 0; k < 5; ++k) d[k] = f[2 * k] | (f[2 * k + 1] << 16);
                     }
         if (t.tube && t.tube_bytes != tb.size() * 4) {
             HIP_TRY(ctx, hipFree(t.tube));
@@ -468,8 +492,8 @@ static int run_stage_one(mulut_ctx *ctx, int stage, const View &in, const View &
     if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || (C == 1 && packed_ok))) mode = kOutPlanarU4;
     else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3 && packed_ok) mode = kOutPackedRGBU4;
     // (merged 16-bit fields hold 4 modes)
-    if (u == 2 && ctx->n_modes <= 4 && ctx->final_kernel != 1 && (unsigned long long)N * C * H * W < (1ull << 32)) {
-        // u == 2 final stage on the tube band (the 1-byte-row kernel family with 4-value rows); flagged sites recomputed from the full table
+    if ((u == 2 || u == 3) && ctx->n_modes <= 4 && ctx->final_kernel != 1 && (unsigned long long)N * C * H * W < (1ull << 32)) {
+        // u == 2 / u == 3 final stage on the tube band (the 1-byte-row kernel family with 4- / 9-value rows); flagged sites recomputed from the full table
         rc = ensure_fix(ctx, (size_t)N * C * (oy1 - oy0) * W);
         if (rc) return rc;
         BandArgs b2;
@@ -479,9 +503,26 @@ static int run_stage_one(mulut_ctx *ctx, int stage, const View &in, const View &
         HIP_TRY(ctx, hipMemsetAsync(ctx->fix, 0, sizeof(uint32_t), st));
         int t2w, t2h;
         stage_u1t_tile(t2w, t2h);
+        StageArgs g = a;                // the gather kernel's launch on the tiles the tube kernel leaves out (its own tiling)
         a.tiles_x = (W + t2w - 1) / t2w;
         a.tiles_y = (oy1 - oy0 + t2h - 1) / t2h;
-        MAIN_KERNEL(ctx, stage, st, launch_stage_u2t(a, b2, ctx->num_cus, ctx->u1t_persist, st));
+        // final_kernel 5: the tube kernel on every tile; otherwise routed by the 1-byte-row family's local-detail statistic -- detailed
+        // 64 x 64 tiles (where most sites would end up on the fix-up list) go to the gather kernel, through device-side marks
+        const bool route = ctx->final_kernel != 5;
+        if (route) {
+            rc = ensure_tlist(ctx, (size_t)N * a.tiles_x * a.tiles_y);
+            if (rc) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->tlist, 0, (16 + (size_t)N * a.tiles_x * a.tiles_y) * sizeof(uint32_t), st));
+            a.tile_count = ctx->tlist;
+            a.tile_list = ctx->tlist + 16;
+            a.verdict_take = 0;
+        }
+        if (u == 2) MAIN_KERNEL(ctx, stage, st, launch_stage_u2t(a, b2, (unsigned)ctx->up_detail_per_1024, ctx->num_cus, ctx->u1t_persist, st));
+        else MAIN_KERNEL(ctx, stage, st, launch_stage_u3t(a, b2, (unsigned)ctx->up_detail_per_1024, ctx->num_cus, ctx->u1t_persist, st));
+        if (route) {
+            g.tile_list = a.tile_list;
+            HIP_TRY(ctx, launch_stage_up(g, u, kOutGeneric, st));
+        }
         return MULUT_OK;
     }
     if (!tube) {
@@ -558,7 +599,7 @@ static int stage_fit_images(const mulut_ctx *ctx, int stage, const View &in, int
         const unsigned long long f = per_image ? (limit - 1) / per_image : fit;
         if (f < fit) fit = f;
     };
-    if (u == 1 || u == 2) cap(1ull << 32, (unsigned long long)C * H * W);
+    if (u == 1 || u == 2 || u == 3) cap(1ull << 32, (unsigned long long)C * H * W);
     if (u == 4 && ctx->final_kernel != 1) {
         cap(1ull << 30, (unsigned long long)H * W);
         if (ctx->final_kernel != 5 && ctx->detail_kernel == 0 && ctx->n_modes <= 3 && in.sX == 1)      // (what detail_slab_supported() asks of a launch)
@@ -682,7 +723,7 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
         if (rc) return rc;
         {
             const bool u1 = ctx->stages > 1 || ctx->scale == 1;
-            rc = ensure_fix(ctx, (size_t)N * H * W * ((u1 || ctx->scale == 2 || ctx->scale == 4) ? (size_t)(C > 3 ? C : 3) : 1));
+            rc = ensure_fix(ctx, (size_t)N * H * W * ((u1 || ctx->scale == 2 || ctx->scale == 3 || ctx->scale == 4) ? (size_t)(C > 3 ? C : 3) : 1));
             if (rc) return rc;
             if (ctx->scale == 4) {
                 stage_band_tile(tw, th);
@@ -699,7 +740,7 @@ int mulut_reserve(mulut_ctx *ctx, int N, int H, int W, int C) {
                     if (rc) return rc;
                 }
             }
-            if (u1) {
+            if (u1 || ctx->scale == 2 || ctx->scale == 3) {      // tile marks of the routed 1-byte-row family (first stages; x2 / x3 final stages)
                 stage_u1_tile(tw, th);
                 rc = ensure_tlist(ctx, (size_t)N * ((W + tw - 1) / tw) * ((H + th - 1) / th));
                 if (rc) return rc;
@@ -898,6 +939,11 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
         ctx->u1_detail_per_1024 = value;
         return MULUT_OK;
     }
+    if (!strcmp(key, "final_stage_detail_per_1024")) {
+        if (value < 0 || value > 1024) return MULUT_EINVAL;
+        ctx->up_detail_per_1024 = value;
+        return MULUT_OK;
+    }
     if (!strcmp(key, "hybrid_oob_per_1024")) {
         if (value < 0 || value > 1024) return MULUT_EINVAL;
         ctx->hybrid_oob_per_1024 = value;
@@ -910,6 +956,7 @@ const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (!ctx || !ctx->configured) return "";
     if (!is_final || ctx->scale == 1) return stage_u1_name(ctx->first_kernel);
     if (ctx->scale == 2 && ctx->n_modes <= 4 && ctx->final_kernel != 1) return "stage_u1t_kernel<2> + stage_up_fix_site_kernel<2>";
+    if (ctx->scale == 3 && ctx->n_modes <= 4 && ctx->final_kernel != 1) return "stage_u1t_kernel<3> + stage_up_fix_site_kernel<3>";
     // (as run_stage decides: the pipelined kernel takes every list that uses all of s, d, y, up to kMaxTube2Modes modes, when the float
     // epilogue is exact for the divisor)
     const bool all3 = strchr(ctx->modes, 's') && strchr(ctx->modes, 'd') && strchr(ctx->modes, 'y');

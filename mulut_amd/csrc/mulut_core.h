@@ -452,12 +452,20 @@ struct TubePair1 {
 };
 constexpr int kTube1BandBytes = ((kTubeSlots * 4 + 15) / 16) * 16;      // 4176
 constexpr int kTube2BandBytes = ((kTubeSlots * 8 + 15) / 16) * 16;      // 8336: u == 2 rows as four 16-bit fields (8 bytes per slot)
+// u == 3 rows: the nine values as ten 16-bit fields e0 e1 e2 e3 e4 e4 e5 e6 e7 e8 -- the centre twice, so that the 180-degree
+// rotation of the 3 x 3 block (element q -> 8 - q) is the reversal of the ten fields (whole dwords reversed, halves swapped) and the
+// passes of rotations r and r + 2 share one accumulator set, as for u == 2 and u == 4.  24 bytes per slot (20 used; 8-byte aligned reads)
+constexpr int kTube3SlotBytes = 24;
+constexpr int kTube3BandBytes = ((kTubeSlots * kTube3SlotBytes + 15) / 16) * 16;      // 24992
+MULUT_HD constexpr int tube3_field(int q) { return q <= 4 ? q : q + 1; }               // field of block element q (the centre's second copy is field 5)
 MULUT_HD uint32_t pixel_code1(uint32_t v) { return ((v & 15u) << 12) | (v >> 4); }
 MULUT_HD uint32_t tube1_key(uint32_t code_pk, uint32_t stride4) { return (code_pk & 0xF000F000u) | pk_dup(stride4); }
-// SHIFT = log2(bytes per slot): 2 for 1-byte rows (one dword per slot), 3 for u == 2 rows (four 16-bit fields per slot)
-template <int SHIFT = 2>
-MULUT_HD void simplex4_tube_pair1(uint32_t k0, uint32_t base_a, uint32_t pb, uint32_t pc, uint32_t pd, TubePair1 &o) {
-    uint32_t k1 = tube1_key(pb, kTubeSB << SHIFT), k2 = tube1_key(pc, kTubeSC << SHIFT), k3 = tube1_key(pd, kTubeSD << SHIFT);
+// SLOT = bytes per slot: 4 for 1-byte rows (one dword per slot), 8 for u == 2 rows (four 16-bit fields per slot) -- a stride then fits
+// the low BYTE of a key -- and 24 for u == 3 rows, whose strides (<= 24 * 27) take the twelve bits under f
+template <int SLOT>
+MULUT_HD void simplex4_tube_pair1_slot(uint32_t k0, uint32_t base_a, uint32_t pb, uint32_t pc, uint32_t pd, TubePair1 &o) {
+    static_assert(SLOT == 4 || SLOT == 8 || SLOT == 24, "slot size");
+    uint32_t k1 = tube1_key(pb, kTubeSB * SLOT), k2 = tube1_key(pc, kTubeSC * SLOT), k3 = tube1_key(pd, kTubeSD * SLOT);
 #if !(defined(MULUT_ABLATE) && MULUT_ABLATE == 32)   /* 32 = timing-only: no sort */
     pk_cmpx_desc(k0, k1);
     pk_cmpx_desc(k2, k3);
@@ -469,13 +477,17 @@ MULUT_HD void simplex4_tube_pair1(uint32_t k0, uint32_t base_a, uint32_t pb, uin
     // 16 * slot summed over the keys (< 16 * 1041); a quarter of it is the byte offset.  One 32-bit shift: both halves
     // are multiples of 16, so no set bit crosses over.
     const uint32_t base16 = pk_mad(pb, pk_dup(16 * kTubeSB), pk_mad(pc, pk_dup(16 * kTubeSC), pk_mad(pd, pk_dup(16 * kTubeSD), base_a)));
-    o.base = base16 >> (4 - SHIFT);
+    o.base = SLOT == 24 ? base16 + (base16 >> 1) : base16 >> (SLOT == 4 ? 2 : 1);      // (24 = 16 * 1.5; the halves are multiples of 16 and stay below 2^16)
     o.ks[0] = k0; o.ks[1] = k1; o.ks[2] = k2;
     o.w[0] = pk_dup(kQ) - f1;
     o.w[1] = f1 - f2;
     o.w[2] = f2 - f3;
     o.w[3] = f3 - f4;
     o.w[4] = f4;
+}
+template <int SHIFT = 2>
+MULUT_HD void simplex4_tube_pair1(uint32_t k0, uint32_t base_a, uint32_t pb, uint32_t pc, uint32_t pd, TubePair1 &o) {
+    simplex4_tube_pair1_slot<(1 << SHIFT)>(k0, base_a, pb, pc, pd, o);
 }
 
 // ---- slab pairs: the full table, two anchor slabs at a time (detailed content) ----------------------------

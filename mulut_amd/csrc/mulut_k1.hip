@@ -240,8 +240,9 @@ constexpr int K1T_TW = 64, K1T_TH = 64;
 // waves per SIMD.  The instance with the shipped mode list compiled in needs 59 VGPRs: two 1024-thread workgroups share a CU at 8 waves per
 // SIMD (the half-rate instruction class issues at 2.62 cycles per instruction and SIMD there, 2.83 at 6: profiles/r01_ubench_valu_issue_cost.txt).
 // The run-time-list instances need 80: three 512-thread workgroups, 6 waves per SIMD.
-__host__ __device__ constexpr int u1t_threads(int U, int pats) { return (U == 1 && pats != 0) ? 1024 : 512; }
-__host__ __device__ constexpr int u1t_waves(int U, int pats) { return (U == 1 && pats != 0) ? 8 : 6; }
+// u == 3 (24,992-byte bands: one workgroup per CU): 1024 threads, 4 waves per SIMD.
+__host__ __device__ constexpr int u1t_threads(int U, int pats) { return ((U == 1 && pats != 0) || U == 3) ? 1024 : 512; }
+__host__ __device__ constexpr int u1t_waves(int U, int pats) { return U == 3 ? 4 : (U == 1 && pats != 0) ? 8 : 6; }
 constexpr int K1T_PW = K1T_TW + 2 * kHalo, K1T_PH = K1T_TH + 2 * kHalo;
 constexpr int kU1tTileBytes = 3 * K1T_PH * K1T_PW * 2;
 constexpr int kU1tDirtyBytes = 3 * K1T_TH * (K1T_TW / 4);          // one byte per four-pixel group of the tile
@@ -254,6 +255,13 @@ template <> struct U1tAcc<1> { int v; __device__ __forceinline__ void clear() { 
 template <> struct U1tAcc<2> {
     uint32_t a02[2], a13[2];
     __device__ __forceinline__ void clear() { a02[0] = a02[1] = a13[0] = a13[1] = 0; }
+};
+template <> struct U1tAcc<3> {      // ten fields per set (mulut_core.h: kTube3BandBytes)
+    uint32_t a02[5], a13[5];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a02[k] = a13[k] = 0;
+    }
 };
 __device__ __forceinline__ uint2 lds_u64(uint32_t addr) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -273,12 +281,13 @@ __device__ __forceinline__ uint32_t halves_lo_hi(uint32_t a, uint32_t b) {
 __host__ __device__ constexpr int u1t_modes(int pats) { return pats & 3; }
 __host__ __device__ constexpr int u1t_pat(int pats, int m) { return (pats >> (2 + 2 * m)) & 3; }
 constexpr int kU1tPatsSDY = 3 | (0 << 2) | (1 << 4) | (2 << 6);
-template <int U> __host__ __device__ constexpr int u1t_band_bytes() { return U == 1 ? kTube1BandBytes : kTube2BandBytes; }
+template <int U> __host__ __device__ constexpr int u1t_band_bytes() { return U == 1 ? kTube1BandBytes : U == 2 ? kTube2BandBytes : kTube3BandBytes; }
+template <int U> __host__ __device__ constexpr int u1t_slot_bytes() { return U == 1 ? 4 : U == 2 ? 8 : kTube3SlotBytes; }
 
 // rotations R and R + 2 of the pixel at window column I + 2, pattern PAT
 template <int U, int PAT, int R, int I, int NW>
 __device__ __forceinline__ void u1t_pair(const uint32_t (&win)[5][NW], uint32_t k0, uint32_t base_a, U1tAcc<U> &acc) {
-    constexpr int SHIFT = U == 1 ? 2 : 3;
+    constexpr int SLOT = u1t_slot_bytes<U>();
     constexpr int BAND = PAT * u1t_band_bytes<U>();      // LDS byte address of this pattern's band
     constexpr int yb = rot_dy(R, kPatDi[PAT][0], kPatDj[PAT][0]), xb = rot_dx(R, kPatDi[PAT][0], kPatDj[PAT][0]);
     constexpr int yc = rot_dy(R, kPatDi[PAT][1], kPatDj[PAT][1]), xc = rot_dx(R, kPatDi[PAT][1], kPatDj[PAT][1]);
@@ -287,17 +296,22 @@ __device__ __forceinline__ void u1t_pair(const uint32_t (&win)[5][NW], uint32_t 
     const uint32_t pc = win_pair<2 + yc, I + 2 + xc, 2 - yc, I + 2 - xc, NW>(win);
     const uint32_t pd = win_pair<2 + yd, I + 2 + xd, 2 - yd, I + 2 - xd, NW>(win);
     TubePair1 bp;
-    simplex4_tube_pair1<SHIFT>(k0, base_a, pb, pc, pd, bp);
-    // byte offsets of rows 0..3 of both passes, unpacked: row j + 1 = row j + stride byte of sorted key j
+    simplex4_tube_pair1_slot<SLOT>(k0, base_a, pb, pc, pd, bp);
+    // byte offsets of rows 0..3 of both passes, unpacked: row j + 1 = row j + stride of sorted key j (its low byte; twelve bits for u == 3)
     uint32_t aa[4], ab[4];
     aa[0] = bp.base & 0xFFFFu;
     ab[0] = bp.base >> 16;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        aa[j + 1] = add_byte<0>(aa[j], bp.ks[j]);
-        ab[j + 1] = add_byte<2>(ab[j], bp.ks[j]);
+        if constexpr (U == 3) {
+            aa[j + 1] = aa[j] + (bp.ks[j] & 0xFFFu);
+            ab[j + 1] = ab[j] + ((bp.ks[j] >> 16) & 0xFFFu);
+        } else {
+            aa[j + 1] = add_byte<0>(aa[j], bp.ks[j]);
+            ab[j + 1] = add_byte<2>(ab[j], bp.ks[j]);
+        }
     }
-    constexpr int kRow4 = kTubeAll << SHIFT;
+    constexpr int kRow4 = kTubeAll * SLOT;
     if constexpr (U == 1) {
         uint32_t xa[5], xb2[5];
 #pragma unroll
@@ -312,6 +326,26 @@ __device__ __forceinline__ void u1t_pair(const uint32_t (&win)[5][NW], uint32_t 
             typedef short s16x2 __attribute__((ext_vector_type(2)));
             const uint32_t t = halves_lo_hi(xa[j], xb2[j]);     // value of pass A | value of pass B
             acc.v = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, t), __builtin_bit_cast(s16x2, bp.w[j]), acc.v, false);
+        }
+    } else if constexpr (U == 3) {
+        // pass A = rotation R (fields in place, weight = low half), pass B = rotation R + 2 (field p lands on 9 - p: dwords reversed,
+        // halves swapped, weight = high half)
+        uint32_t (&ac)[5] = R == 0 ? acc.a02 : acc.a13;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t pa = aa[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4)), pb2 = ab[j < 4 ? j : 0] + (uint32_t)(BAND + (j < 4 ? 0 : kRow4));
+            const uint2 a01 = lds_u64(pa), a23 = lds_u64(pa + 8u), b01 = lds_u64(pb2), b23 = lds_u64(pb2 + 8u);
+            const uint32_t a4 = lds_u32(pa + 16u), b4 = lds_u32(pb2 + 16u);
+            pk_mac<0, false>(ac[0], a01.x, bp.w[j]);
+            pk_mac<0, false>(ac[1], a01.y, bp.w[j]);
+            pk_mac<0, false>(ac[2], a23.x, bp.w[j]);
+            pk_mac<0, false>(ac[3], a23.y, bp.w[j]);
+            pk_mac<0, false>(ac[4], a4, bp.w[j]);
+            pk_mac<1, true>(ac[4], b01.x, bp.w[j]);
+            pk_mac<1, true>(ac[3], b01.y, bp.w[j]);
+            pk_mac<1, true>(ac[2], b23.x, bp.w[j]);
+            pk_mac<1, true>(ac[1], b23.y, bp.w[j]);
+            pk_mac<1, true>(ac[0], b4, bp.w[j]);
         }
     } else {
         uint2 xa[5], xb2[5];
@@ -351,12 +385,12 @@ __device__ __forceinline__ void u1t_mode(const uint32_t (&win)[5][3], uint32_t &
 // lgkmcnt(0) in the hot loop, and its three pattern bodies share tails through extra address adds).  PATS == 0: `pats_rt` holds
 // the patterns of the list, two bits per mode.
 template <int U, int I, int PATS>
-__device__ __forceinline__ uint32_t u1t_pixel(const StageArgs &a, uint32_t pats_rt, const uint32_t (&win)[5][3]) {
+__device__ __forceinline__ uint32_t u1t_pixel(const StageArgs &a, uint32_t pats_rt, const uint32_t (&win)[5][3], uint32_t (&rows3)[3]) {
     U1tAcc<U> acc;
     acc.clear();
     // anchor terms, the same for every mode and rotation of the pixel
     const uint32_t ca_pk = win_pair<2, I + 2, 2, I + 2, 3>(win);
-    uint32_t k0 = tube1_key(ca_pk, kTubeSA << (U == 1 ? 2 : 3));
+    uint32_t k0 = tube1_key(ca_pk, kTubeSA * u1t_slot_bytes<U>());
     const uint32_t base_a = pk_mad(ca_pk, pk_dup(16 * kTubeSA), 0u);
     if constexpr (PATS != 0) {
         static_for<0, u1t_modes(PATS)>([&](auto MI) {
@@ -379,6 +413,19 @@ __device__ __forceinline__ uint32_t u1t_pixel(const StageArgs &a, uint32_t pats_
         if (a.use_fma)       // wave-uniform: fused float epilogue proven exact; v_cvt_pk_u8_f32 rounds to nearest even and saturates
             return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)acc.v, a.inv_d, a.epi_c), 0u, 0u);
         return rhe_clip_u8(acc.v + a.bias_num, a.div);
+    } else if constexpr (U == 3) {
+        // block value (sy, sx) = field of element 3 sy + sx of the (0,2) set + field of element (2 - sx) 3 + sy of the (1,3) set, minus the
+        // +128 bias of the rows; the three bytes of block row sy in rows3[sy]
+        const int unbias = 128 * kQ * 4 * a.M - a.bias_num;
+        auto fld = [](const uint32_t (&v)[5], int q) { return (int)((v[tube3_field(q) >> 1] >> (16 * (tube3_field(q) & 1))) & 0xFFFFu); };
+#pragma unroll
+        for (int sy = 0; sy < 3; ++sy) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) r |= (uint32_t)rhe_clip_u8(fld(acc.a02, 3 * sy + sx) + fld(acc.a13, (2 - sx) * 3 + sy) - unbias, a.div) << (8 * sx);
+            rows3[sy] = r;
+        }
+        return 0u;
     } else {
         // block value (sy, sx) = field 2 sy + sx of the (0,2) set + field (1 - sx) 2 + sy of the (1,3) set, minus the +128 bias of the rows
         const int unbias = 128 * kQ * 4 * a.M - a.bias_num;
@@ -632,18 +679,38 @@ __global__ void __launch_bounds__(u1t_threads(U, PATS), u1t_waves(U, PATS)) stag
                 int ty, tx4;
                 coords(ty, tx4);
                 const int y = y0 + ty, x = x0 + tx4;
-                if (U == 2 && x + 2 * it >= a.W) break;
+                if (U >= 2 && x + 2 * it >= a.W) break;
                 uint32_t win[5][3];
                 const uint32_t *row = (const uint32_t *)(s_tile + 2 * ((c * PH + ty) * PW + tx4 + 2 * it));
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
                     win[q][0] = row[q * (PW / 2)]; win[q][1] = row[q * (PW / 2) + 1]; win[q][2] = row[q * (PW / 2) + 2];
                 }
-                uint32_t b0 = u1t_pixel<U, 0, PATS>(a, pats_rt, win);
-                asm volatile("" : "+v"(b0), "+v"(win[2][1]));       // the second pixel starts after the first is done
-                const uint32_t b1 = u1t_pixel<U, 1, PATS>(a, pats_rt, win);
+                uint32_t r0[3] = {0u, 0u, 0u}, r1[3] = {0u, 0u, 0u};      // u == 3: the pixels' three block rows, three bytes each
+                uint32_t b0 = u1t_pixel<U, 0, PATS>(a, pats_rt, win, r0);
+                if constexpr (U == 3) asm volatile("" : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(win[2][1]));
+                else asm volatile("" : "+v"(b0), "+v"(win[2][1]));       // the second pixel starts after the first is done
+                const uint32_t b1 = u1t_pixel<U, 1, PATS>(a, pats_rt, win, r1);
                 if constexpr (U == 1) {
                     packed |= (b0 | (b1 << 8)) << (16 * it);
+                } else if constexpr (U == 3) {
+                    // two 3 x 3 blocks side by side: HR rows 3y .. 3y + 2, columns 3 (x + 2 it) .. + 5
+                    const int xo = 3 * (x + 2 * it);
+                    const bool both = x + 2 * it + 1 < a.W;
+#pragma unroll
+                    for (int sy = 0; sy < 3; ++sy) {
+                        uint8_t *d = const_cast<uint8_t *>(view_addr(a.out, n, c, 3 * y + sy, xo));
+                        const uint32_t lo = r0[sy] | (r1[sy] << 24), hi = r1[sy] >> 8;      // bytes 0..3, 4..5 of the six
+                        if (a.out.sX == 1 && both && (((uintptr_t)d) & 1) == 0) {
+                            ((uint16_t *)d)[0] = (uint16_t)lo;
+                            ((uint16_t *)d)[1] = (uint16_t)(lo >> 16);
+                            ((uint16_t *)d)[2] = (uint16_t)hi;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 6; ++i)
+                                if (i < 3 || both) d[i * a.out.sX] = (uint8_t)((i < 4 ? lo >> (8 * i) : hi >> (8 * (i - 4))));
+                        }
+                    }
                 } else {
                     // two 2 x 2 blocks side by side: HR rows 2y and 2y + 1, columns 2 (x + 2 it) .. + 3
                     const int xo = 2 * (x + 2 * it);
@@ -796,7 +863,7 @@ static hipError_t launch_u1t_t(const StageArgs &a, const BandArgs &b, unsigned d
     const bool sdy = a.M == 3 && a.di[0][0] == 0 && a.dj[0][0] == 1 && a.dj[1][0] == 2 && a.di[2][0] == 1 && a.dj[2][0] == 1;
     auto kern = sdy ? stage_u1t_kernel<U, kU1tPatsSDY> : stage_u1t_kernel<U, 0>;
     {
-        const hipError_t e = raise_lds_limit((const void *)kern, 80 * 1024);
+        const hipError_t e = raise_lds_limit((const void *)kern, U == 3 ? 112 * 1024 : 80 * 1024);
         if (e != hipSuccess) return e;
     }
     const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
@@ -873,12 +940,22 @@ __global__ void __launch_bounds__(256) stage_up_fix_site_kernel(StageArgs a) {
 }
 
 // the same kernel family on a FINAL stage with u == 2 (4-value rows, 2 x 2 output blocks): b.band[m] = 8-byte-per-slot
-// tube band; no tile routing; flagged sites go to stage_up_fix_site_kernel through a.fix_list
-hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, int num_cus, int persist_per_cu, hipStream_t st) {
-    if (a.C > 3 || a.M > 4 || !a.fix_list || !a.fix_count || a.verdict_take >= 0) return hipErrorInvalidValue;
-    hipError_t e = launch_u1t_t<2>(a, b, 0u, num_cus, persist_per_cu, st);
+// tube band; flagged sites go to stage_up_fix_site_kernel through a.fix_list; a.verdict_take >= 0: tiles whose local-detail statistic
+// exceeds detail_per_1024 are marked in a.tile_list and left out (the caller runs the gather kernel on them)
+hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st) {
+    if (a.C > 3 || a.M > 4 || !a.fix_list || !a.fix_count || (a.verdict_take >= 0 && !a.tile_list)) return hipErrorInvalidValue;
+    hipError_t e = launch_u1t_t<2>(a, b, detail_per_1024, num_cus, persist_per_cu, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(stage_up_fix_site_kernel<2>, dim3((unsigned)(4 * num_cus)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// and with u == 3 (9-value rows as ten 16-bit fields, 24 bytes per slot; 3 x 3 output blocks)
+hipError_t launch_stage_u3t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st) {
+    if (a.C > 3 || a.M > 4 || !a.fix_list || !a.fix_count || (a.verdict_take >= 0 && !a.tile_list)) return hipErrorInvalidValue;
+    hipError_t e = launch_u1t_t<3>(a, b, detail_per_1024, num_cus, persist_per_cu, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(stage_up_fix_site_kernel<3>, dim3((unsigned)(4 * num_cus)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -115,7 +115,11 @@ hipError_t launch_stage_u1(const StageArgs &a, hipStream_t st, int variant);
 // a.tile_list and the sites that may have left the tube in a.fix_list
 hipError_t launch_stage_u1t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st);
 // final stage with u == 2 on the tube band (8 bytes per slot: four 16-bit fields), + its site fix-up
-hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, int num_cus, int persist_per_cu, hipStream_t st);
+// (a.verdict_take >= 0: routed -- tiles above detail_per_1024 are marked in a.tile_list and left to launch_stage_up, which then
+// computes only marked tiles)
+hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st);
+// final stage with u == 3 on the tube band (24 bytes per slot: the nine values as ten 16-bit fields, mulut_core.h), + its site fix-up
+hipError_t launch_stage_u3t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st);
 // full-table kernel over the tiles marked in a.tile_list[]
 hipError_t launch_stage_u1w_list(const StageArgs &a, int num_cus, hipStream_t st);
 // recompute the sites in a.fix_list[0 .. *a.fix_count) from the full tables (1-byte rows)

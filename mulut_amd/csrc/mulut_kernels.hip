@@ -247,6 +247,12 @@ __global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
         x0 = vx * 64 + (sub & 1) * TW;
     } else {
         decode_tile(a, id, n, y0, x0, TW, TH);
+        // routed launch of a u == 2 / u == 3 final stage: only the 64 x 64 tiles the tube-band kernel (stage_u1t_kernel) marked as detailed
+        // and left out (its tile grid starts at (oy0, 0) like this one, and 64 x 64 is a multiple of TW x TH)
+        if (a.tile_list) {
+            const int kx = (a.W + 63) >> 6, ky = (a.oy1 - a.oy0 + 63) >> 6;
+            if (a.tile_list[(n * ky + ((y0 - a.oy0) >> 6)) * kx + (x0 >> 6)] == 0u) return;      // block-uniform
+        }
     }
     {   // this group's tile (load_tile, strided by the group's NT threads)
         const int total = a.C * PH * PW;

@@ -289,6 +289,59 @@ extern "C" long emul_check_slab_pair(int step) {
     return bad;
 }
 
+// Tube pairs of the 1-byte-row kernel family (simplex4_tube_pair1_slot: slots of 4, 8 and 24 bytes = u 1, 2, 3): for every in-tube key
+// combination the packed pair math must give byte offsets SLOT * (tube slot of the scalar simplex row) with the same weight per row --
+// strides from the low byte of the sorted keys (4, 8) or their low twelve bits (24), as stage_u1t_kernel unpacks them.
+template <int SLOT>
+static long check_tube_pair1_slot(int step) {
+    long bad = 0;
+    for (int va = 0; va < 256; va += step)
+        for (int vb = 0; vb < 256; vb += step)
+            for (int vc = 0; vc < 256; vc += step)
+                for (int vd = 0; vd < 256; vd += 1) {
+                    const int vb2 = (vb * 7 + 3) & 255, vc2 = (vc * 5 + 11) & 255, vd2 = 255 - vd;
+                    const uint32_t ca = pk_dup(pixel_code1((uint32_t)va));
+                    TubePair1 tp;
+                    simplex4_tube_pair1_slot<SLOT>(tube1_key(ca, (uint32_t)(kTubeSA * SLOT)), pk_mad(ca, pk_dup(16 * kTubeSA), 0u),
+                                                   pixel_code1((uint32_t)vb) | (pixel_code1((uint32_t)vb2) << 16),
+                                                   pixel_code1((uint32_t)vc) | (pixel_code1((uint32_t)vc2) << 16),
+                                                   pixel_code1((uint32_t)vd) | (pixel_code1((uint32_t)vd2) << 16), tp);
+                    for (int half = 0; half < 2; ++half) {
+                        const int b = half ? vb2 : vb, c = half ? vc2 : vc, d = half ? vd2 : vd;
+                        const int ha = va >> 4, hb = b >> 4, hc = c >> 4, hd = d >> 4;
+                        if (imax(imax(ha, hb), imax(hc, hd)) - imin(imin(ha, hb), imin(hc, hd)) > 1) continue;      // (the in-tube test is the caller's)
+                        int idx[5], w[5];
+                        simplex4(va, b, c, d, idx, w);
+                        uint32_t off[5];
+                        off[0] = half ? (tp.base >> 16) : (tp.base & 0xFFFFu);
+                        for (int j = 0; j < 3; ++j) {
+                            const uint32_t k = half ? (tp.ks[j] >> 16) : (tp.ks[j] & 0xFFFFu);
+                            off[j + 1] = off[j] + (SLOT == 24 ? (k & 0xFFFu) : (k & 0xFFu));
+                        }
+                        off[4] = off[0] + (uint32_t)(kTubeAll * SLOT);
+                        for (int j = 0; j < 5; ++j) {
+                            int ws = 0, wq = 0;
+                            const int A = idx[j] / kStrideA, B = (idx[j] / kStrideB) % kL, C = (idx[j] / kStrideC) % kL, D = idx[j] % kL;
+                            const uint32_t want = (uint32_t)(tube_slot(A, B, C, D) * SLOT);
+                            for (int i = 0; i < 5; ++i) {
+                                if (idx[i] == idx[j]) ws += w[i];
+                                if (off[i] == want) wq += (int)(half ? (tp.w[i] >> 16) : (tp.w[i] & 0xFFFFu));
+                            }
+                            if (ws != wq || want + (uint32_t)SLOT > (uint32_t)(kTubeSlots * SLOT)) ++bad;
+                        }
+                    }
+                }
+    return bad;
+}
+extern "C" long emul_check_tube_pair1(int step) {
+    long bad = check_tube_pair1_slot<4>(step) + check_tube_pair1_slot<8>(step) + check_tube_pair1_slot<24>(step);
+    // u == 3 band fields: element q and element 8 - q sit at mirrored fields of the ten (the centre at 4 and 5)
+    for (int q = 0; q < 9; ++q)
+        if (q != 4 && tube3_field(q) + tube3_field(8 - q) != 9) ++bad;
+    if (tube3_field(4) != 4) ++bad;
+    return bad;
+}
+
 // tube band (mulut_core.h): the slot map must be injective on the 991 tube rows and stay inside
 // [0, kTubeSlots) for EVERY key combination; the packed pair math must give, for in-tube passes, the
 // tube slots of the scalar simplex rows with the same weight per row, for every bias the kernels use.

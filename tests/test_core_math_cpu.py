@@ -109,6 +109,13 @@ def test_tube_pair_index_math(emul):
     assert emul.emul_check_tube_pair(5) == 0
 
 
+def test_tube_pair1_index_math_for_every_slot_size(emul):
+    """tube pairs of the 1-byte-row kernel family with 4-, 8- and 24-byte slots (u = 1, 2, 3): byte offsets and weights of the packed pair
+    math == the scalar simplex for every in-tube key combination (sampled); field layout of the u == 3 band"""
+    emul.emul_check_tube_pair1.restype = ctypes.c_long
+    assert emul.emul_check_tube_pair1(5) == 0
+
+
 def test_float_epilogue_validity_table():
     """rhe_f32_valid() outcome per mode count (documented in DESIGN.md): the GPU uses the float epilogue
     only where it is proven exact, so this is informational -- but M = 3 (sdy) must be on the fast path."""

@@ -520,6 +520,42 @@ def test_five_to_eight_modes_on_the_lds_path(modes):
         e.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("stages,modes", [(2, "sdy"), (1, "s"), (2, "ddyy"), (3, "ys")])
+def test_x3_final_stage_on_the_lds_path(stages, modes):
+    """x3 final stages (9-value rows) run on the tube-band kernel family (stage_u1t_kernel<3>: the nine values as ten 16-bit fields, centre
+    twice, so that rotations r and r + 2 share accumulators), flagged sites on the site fix-up kernel: extreme and random tables, smooth +
+    noisy + ragged content, HWC / planar / two channels, against the gather kernel (final_stage_kernel 1) and the oracle."""
+    from mulut_amd import MuLUTEngine
+    rng = np.random.default_rng(30 + stages + len(modes))
+    # 136 columns (a multiple of four: the routed launch -- smooth 64 x 64 tiles on the tube kernel, detailed ones on the gather kernel) and 133
+    img = np.stack([np.concatenate([natural_image(37, 72, 3, seed=s), rng.integers(0, 256, (37, 64, 3), dtype=np.uint8)], axis=1) for s in (1, 2)])
+    for val in (127, -128, None):
+        luts = {}
+        for st in range(1, stages + 1):
+            for m in set(modes):
+                if st < stages:
+                    luts["s%d_%s" % (st, m)] = synthetic_lut(ord(m) + st, 1)
+                else:
+                    luts["s%d_%s" % (st, m)] = np.full((17 ** 4, 9), val, np.int8) if val is not None else rng.integers(-128, 128, (17 ** 4, 9), dtype=np.int8)
+        e = MuLUTEngine(0).configure(stages, modes, 3, 4).set_lut_dict(luts)
+        assert "stage_u1t_kernel<3>" in e.kernel_name(True)
+        want = np.stack([c_oracle.pipeline(luts, stages, modes, 3, im) for im in img])
+        assert want.shape == (2, 111, 408, 3)
+        for sel in (0, 5, 1):           # routed, tube kernel on every tile, gather kernel
+            e.set_tuning("final_stage_kernel", sel)
+            assert np.array_equal(e.pipeline(dev(img)).cpu().numpy(), want), (modes, val, sel)
+            rag = np.ascontiguousarray(img[:, :, 3:])
+            assert np.array_equal(e.pipeline(dev(rag)).cpu().numpy(), np.stack([c_oracle.pipeline(luts, stages, modes, 3, im) for im in rag])), (modes, val, sel, "W=133")
+            got2 = e.pipeline(dev(np.ascontiguousarray(img[..., :2]))).cpu().numpy()
+            assert np.array_equal(got2, want[..., :2]), (modes, val, sel, "C=2")
+            gotp = e.pipeline(dev(np.ascontiguousarray(img.transpose(0, 3, 1, 2))), layout=0).cpu().numpy()
+            assert np.array_equal(gotp, want.transpose(0, 3, 1, 2)), (modes, val, sel, "planar")
+            one = np.ascontiguousarray(img[0, :5, :3, :1])          # smaller than a window
+            assert np.array_equal(e.pipeline(dev(one)).cpu().numpy(), c_oracle.pipeline(luts, stages, modes, 3, one)), (modes, val, sel, "tiny")
+        e.close()
+
+
 def _strip_rank(rank, world, port, q):
     """one rank of the config-3 rehearsal: real engine, strips + halo, gather on rank 0 (gloo moves host memory)"""
     import torch.distributed as dist
