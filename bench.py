@@ -544,7 +544,7 @@ def config4(args, world, rank, local, timed, steps=None):
         "config": {"workload": "config 4: bs 256 x 1x48x48 crops of the D-natural field per GPU per step, shipped tables as the start point",
                    "note": "replicas only: each rank trains its own copy (a data-parallel all-reduce of the six table gradients is not built)",
                    "reference_logged": "7.0 s/iter at batch 320 (models/sr_x2sdy/lutft.log), unspecified 2022 GPU"},
-        "roofline": {"bound": "lds_rmw", "kernel": "ft_stage_bwd4 (final-stage backward: table gradients summed in per-group LDS caches of band rows, evicted into an LDS copy of the tube band, flushed once per workgroup and mode)",
+        "roofline": {"bound": "lds_rmw", "kernel": "ft_stage_bwd4 (final-stage backward: table gradients summed in per-group LDS caches of band rows -- a site's five vertices in flight together --, evicted into an LDS copy of the tube band, flushed once per workgroup and mode; clamp mask from the forward; input gradient in per-group LDS tiles)",
                      "table_gradient_adds_per_step": adds,
                      "achieved": round(adds / (ms * 1e-3) / 1e9, 2), "unit": "G float adds/s (whole step time as the denominator)",
                      "peak": round(256 * 64 / 7.0 * CLOCK_GHZ, 1), "peak_how": "256 CUs x 64 lanes per 7.0 LDS cycles (read + add + write of private addresses, measured: profiles/r03_ubench_lds_atomic.txt) x 2.4 GHz; as ds_add_f32 (48 cycles per wave instruction) the peak would be 819",
