@@ -236,6 +236,11 @@ __global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
     const int lt = threadIdx.x;
     const int sub = HY ? (blockIdx.x & 3) : 0;
     uint8_t *s_img = smem;
+    // routed launch of a u == 2 / u == 3 final stage (a.tile_list set, not HY): one workgroup per 64 x 64 tile of the tube-band kernel
+    // (stage_u1t_kernel: its tile grid starts at (oy0, 0) like this one); it leaves at once unless that kernel marked the tile as
+    // detailed and left it out, else walks the tile's TW x TH sub-tiles
+    const bool routed = !HY && a.tile_list != nullptr;
+    int n_sub = 1, ky0 = 0, kx0 = 0;
     if constexpr (HY) {
         if ((int)a.verdict[id] != a.verdict_take) return;              // block-uniform
         int b = id;
@@ -245,14 +250,25 @@ __global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
         n = b / a.vt_y;
         y0 = a.oy0 + vy * 16 + (sub >> 1) * TH;
         x0 = vx * 64 + (sub & 1) * TW;
+    } else if (routed) {
+        if (a.tile_list[id] == 0u) return;                              // block-uniform
+        const int kx = (a.W + 63) >> 6, ky = (a.oy1 - a.oy0 + 63) >> 6;
+        int b = id;
+        kx0 = (b % kx) * 64;
+        b /= kx;
+        ky0 = a.oy0 + (b % ky) * 64;
+        n = b / ky;
+        n_sub = (64 / TW) * (64 / TH);
+        y0 = ky0; x0 = kx0;
     } else {
         decode_tile(a, id, n, y0, x0, TW, TH);
-        // routed launch of a u == 2 / u == 3 final stage: only the 64 x 64 tiles the tube-band kernel (stage_u1t_kernel) marked as detailed
-        // and left out (its tile grid starts at (oy0, 0) like this one, and 64 x 64 is a multiple of TW x TH)
-        if (a.tile_list) {
-            const int kx = (a.W + 63) >> 6, ky = (a.oy1 - a.oy0 + 63) >> 6;
-            if (a.tile_list[(n * ky + ((y0 - a.oy0) >> 6)) * kx + (x0 >> 6)] == 0u) return;      // block-uniform
-        }
+    }
+    for (int q = 0; q < n_sub; ++q) {
+    if (routed) {
+        y0 = ky0 + (q / (64 / TW)) * TH;
+        x0 = kx0 + (q % (64 / TW)) * TW;
+        if (y0 >= a.oy1 || x0 >= a.W) continue;                         // block-uniform
+        if (q) __syncthreads();                                         // everyone is done with the previous sub-tile's pixels
     }
     {   // this group's tile (load_tile, strided by the group's NT threads)
         const int total = a.C * PH * PW;
@@ -268,7 +284,7 @@ __global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
 
     const int tx = lt % TW, ty = lt / TW;
     const int y = y0 + ty, x = x0 + tx;
-    if (y >= a.oy1 || x >= a.W) return;
+    if (y >= a.oy1 || x >= a.W) continue;      // (no barrier below in this trip; the next trip's barrier is reached by every thread)
 
     uint32_t oR[U], oG[U], oB[U];
     for (int c = 0; c < a.C; ++c) {
@@ -297,6 +313,7 @@ __global__ void __launch_bounds__(TW *TH, 4) stage_up_kernel(StageArgs a) {
         if constexpr (OUT == kOutPackedRGBU4) keep_rgb<U>(c, o, oR, oG, oB);
     }
     if constexpr (OUT == kOutPackedRGBU4) store_rgb<U>(a, n, y, x, oR, oG, oB);
+    }
 }
 
 constexpr int K2_TW = 32, K2_TH = 8;
@@ -325,7 +342,8 @@ static hipError_t launch_up(const StageArgs &a, hipStream_t st) {
             return hipErrorInvalidValue;
         }
     }
-    const long long nb = (long long)a.N * a.tiles_x * a.tiles_y;
+    // a.tile_list set: routed launch, one workgroup per 64 x 64 tile of the tube-band kernel that wrote the marks
+    const long long nb = a.tile_list ? (long long)a.N * ((a.W + 63) >> 6) * ((a.oy1 - a.oy0 + 63) >> 6) : (long long)a.N * a.tiles_x * a.tiles_y;
     if (nb <= 0 || nb > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL((stage_up_kernel<U, OUT, K2_TW, K2_TH, false>), dim3((unsigned)nb), dim3(K2_TW * K2_TH), tile_bytes, st, a);
     return hipGetLastError();
