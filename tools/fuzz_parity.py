@@ -71,6 +71,7 @@ def main():
         e.set_tuning("detail_kernel", int(rng.integers(0, 4) == 0))      # mostly the anchor-slab kernel (the default)
         e.set_tuning("stat_from_first_stage", int(rng.integers(0, 4) != 0))      # mostly on (the default)
         e.set_tuning("first_stage_detail_per_1024", int(rng.choice([0, 64, 256, 1024])))
+        e.set_tuning("final_stage_detail_per_1024", int(rng.choice([0, 8, 64, 1024])))      # routing of the x2 / x3 final stages
         n = int(rng.integers(1, 4))
         imgs = np.stack([content(rng, int(rng.integers(0, 5)), h, w, C) for _ in range(n)])
         want = np.stack([c_oracle.pipeline(luts, stages, modes, scale, im) for im in imgs])
