@@ -186,7 +186,7 @@ int mulut_eval_y(int device, const void *gt_hwc, const void *out_hwc, int H, int
  *   bands of all modes resident in LDS; samples with a pass outside the tube are recomputed from the full table through a device
  *   work list), 6 = hybrid: a per-tile statistic sends smooth 64x16 tiles to the tube kernel and detailed ones to the
  *   detailed-tile path.  (2-4: the band / expanded-band kernels of rounds 1-2, retired: MULUT_EINVAL.)
- *   Scales 2 and 3 (<= 4 modes): 0 = the tube-band kernel of the 1-byte-row family with 4- / 9-value rows (stage_u1t_kernel<2>, <3>) on the
+ *   Scales 2 and 3: 0 = the tube-band kernel of the 1-byte-row family with 4- / 9-value rows (stage_u1t_kernel<2>, <3>) on the
  *   64x64 tiles its local-detail statistic calls smooth, the gather kernel on the others (device-side tile marks; threshold
  *   "final_stage_detail_per_1024", as "first_stage_detail_per_1024" below); 5 = the tube-band kernel on every tile; 1 = the gather kernel on every tile.
  * "tube_pipelined": 1 (default) = stage_tube2_kernel where the mode list uses all of s, d, y (any order, repeats, up to 8 modes:

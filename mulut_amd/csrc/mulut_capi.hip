@@ -491,8 +491,7 @@ static int run_stage_one(mulut_ctx *ctx, int stage, const View &in, const View &
     int mode = kOutGeneric;
     if (u == 4 && (out_layout == MULUT_LAYOUT_CHW || (C == 1 && packed_ok))) mode = kOutPlanarU4;
     else if (u == 4 && out_layout == MULUT_LAYOUT_HWC && C == 3 && packed_ok) mode = kOutPackedRGBU4;
-    // (merged 16-bit fields hold 4 modes)
-    if ((u == 2 || u == 3) && ctx->n_modes <= 4 && ctx->final_kernel != 1 && (unsigned long long)N * C * H * W < (1ull << 32)) {
+    if ((u == 2 || u == 3) && ctx->final_kernel != 1 && (unsigned long long)N * C * H * W < (1ull << 32)) {
         // u == 2 / u == 3 final stage on the tube band (the 1-byte-row kernel family with 4- / 9-value rows); flagged sites recomputed from the full table
         rc = ensure_fix(ctx, (size_t)N * C * (oy1 - oy0) * W);
         if (rc) return rc;
@@ -955,8 +954,8 @@ int mulut_set_tuning(mulut_ctx *ctx, const char *key, int value) {
 const char *mulut_kernel_name(const mulut_ctx *ctx, int is_final) {
     if (!ctx || !ctx->configured) return "";
     if (!is_final || ctx->scale == 1) return stage_u1_name(ctx->first_kernel);
-    if (ctx->scale == 2 && ctx->n_modes <= 4 && ctx->final_kernel != 1) return "stage_u1t_kernel<2> + stage_up_fix_site_kernel<2>";
-    if (ctx->scale == 3 && ctx->n_modes <= 4 && ctx->final_kernel != 1) return "stage_u1t_kernel<3> + stage_up_fix_site_kernel<3>";
+    if (ctx->scale == 2 && ctx->final_kernel != 1) return "stage_u1t_kernel<2> + stage_up_fix_site_kernel<2>";
+    if (ctx->scale == 3 && ctx->final_kernel != 1) return "stage_u1t_kernel<3> + stage_up_fix_site_kernel<3>";
     // (as run_stage decides: the pipelined kernel takes every list that uses all of s, d, y, up to kMaxTube2Modes modes, when the float
     // epilogue is exact for the divisor)
     const bool all3 = strchr(ctx->modes, 's') && strchr(ctx->modes, 'd') && strchr(ctx->modes, 'y');

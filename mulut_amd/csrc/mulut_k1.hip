@@ -943,7 +943,7 @@ __global__ void __launch_bounds__(256) stage_up_fix_site_kernel(StageArgs a) {
 // tube band; flagged sites go to stage_up_fix_site_kernel through a.fix_list; a.verdict_take >= 0: tiles whose local-detail statistic
 // exceeds detail_per_1024 are marked in a.tile_list and left out (the caller runs the gather kernel on them)
 hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st) {
-    if (a.C > 3 || a.M > 4 || !a.fix_list || !a.fix_count || (a.verdict_take >= 0 && !a.tile_list)) return hipErrorInvalidValue;
+    if (a.C > 3 || a.M > kMaxModes || !a.fix_list || !a.fix_count || (a.verdict_take >= 0 && !a.tile_list)) return hipErrorInvalidValue;      // (a merged pair of rotations sums to <= 8160 per mode in its unsigned 16-bit field: 8 modes fit)
     hipError_t e = launch_u1t_t<2>(a, b, detail_per_1024, num_cus, persist_per_cu, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(stage_up_fix_site_kernel<2>, dim3((unsigned)(4 * num_cus)), dim3(256), 0, st, a);
@@ -952,7 +952,7 @@ hipError_t launch_stage_u2t(const StageArgs &a, const BandArgs &b, unsigned deta
 
 // and with u == 3 (9-value rows as ten 16-bit fields, 24 bytes per slot; 3 x 3 output blocks)
 hipError_t launch_stage_u3t(const StageArgs &a, const BandArgs &b, unsigned detail_per_1024, int num_cus, int persist_per_cu, hipStream_t st) {
-    if (a.C > 3 || a.M > 4 || !a.fix_list || !a.fix_count || (a.verdict_take >= 0 && !a.tile_list)) return hipErrorInvalidValue;
+    if (a.C > 3 || a.M > kMaxModes || !a.fix_list || !a.fix_count || (a.verdict_take >= 0 && !a.tile_list)) return hipErrorInvalidValue;      // (a merged pair of rotations sums to <= 8160 per mode in its unsigned 16-bit field: 8 modes fit)
     hipError_t e = launch_u1t_t<3>(a, b, detail_per_1024, num_cus, persist_per_cu, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(stage_up_fix_site_kernel<3>, dim3((unsigned)(4 * num_cus)), dim3(256), 0, st, a);

@@ -521,13 +521,15 @@ def test_five_to_eight_modes_on_the_lds_path(modes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("stages,modes", [(2, "sdy"), (1, "s"), (2, "ddyy"), (3, "ys")])
-def test_x3_final_stage_on_the_lds_path(stages, modes):
+@pytest.mark.parametrize("scale,stages,modes", [(3, 2, "sdy"), (3, 1, "s"), (3, 2, "ddyy"), (3, 3, "ys"), (3, 2, "sdysdysd"), (3, 1, "yyyyy"),
+                                                (2, 2, "sdysdysd"), (2, 1, "ddddd")])
+def test_x3_final_stage_on_the_lds_path(scale, stages, modes):
     """x3 final stages (9-value rows) run on the tube-band kernel family (stage_u1t_kernel<3>: the nine values as ten 16-bit fields, centre
-    twice, so that rotations r and r + 2 share accumulators), flagged sites on the site fix-up kernel: extreme and random tables, smooth +
-    noisy + ragged content, HWC / planar / two channels, against the gather kernel (final_stage_kernel 1) and the oracle."""
+    twice, so that rotations r and r + 2 share accumulators), flagged sites on the site fix-up kernel: extreme and random tables (up to eight
+    modes: a merged pair of rotations then fills its unsigned 16-bit field to 65280), smooth + noisy + ragged content, HWC / planar / two
+    channels, against the gather kernel (final_stage_kernel 1) and the oracle.  The x2 instance with more than four modes rides along."""
     from mulut_amd import MuLUTEngine
-    rng = np.random.default_rng(30 + stages + len(modes))
+    rng = np.random.default_rng(30 + stages + len(modes) + scale)
     # 136 columns (a multiple of four: the routed launch -- smooth 64 x 64 tiles on the tube kernel, detailed ones on the gather kernel) and 133
     img = np.stack([np.concatenate([natural_image(37, 72, 3, seed=s), rng.integers(0, 256, (37, 64, 3), dtype=np.uint8)], axis=1) for s in (1, 2)])
     for val in (127, -128, None):
@@ -537,22 +539,22 @@ def test_x3_final_stage_on_the_lds_path(stages, modes):
                 if st < stages:
                     luts["s%d_%s" % (st, m)] = synthetic_lut(ord(m) + st, 1)
                 else:
-                    luts["s%d_%s" % (st, m)] = np.full((17 ** 4, 9), val, np.int8) if val is not None else rng.integers(-128, 128, (17 ** 4, 9), dtype=np.int8)
-        e = MuLUTEngine(0).configure(stages, modes, 3, 4).set_lut_dict(luts)
-        assert "stage_u1t_kernel<3>" in e.kernel_name(True)
-        want = np.stack([c_oracle.pipeline(luts, stages, modes, 3, im) for im in img])
-        assert want.shape == (2, 111, 408, 3)
+                    luts["s%d_%s" % (st, m)] = np.full((17 ** 4, scale * scale), val, np.int8) if val is not None else rng.integers(-128, 128, (17 ** 4, scale * scale), dtype=np.int8)
+        e = MuLUTEngine(0).configure(stages, modes, scale, 4).set_lut_dict(luts)
+        assert "stage_u1t_kernel<%d>" % scale in e.kernel_name(True)
+        want = np.stack([c_oracle.pipeline(luts, stages, modes, scale, im) for im in img])
+        assert want.shape == (2, 37 * scale, 136 * scale, 3)
         for sel in (0, 5, 1):           # routed, tube kernel on every tile, gather kernel
             e.set_tuning("final_stage_kernel", sel)
             assert np.array_equal(e.pipeline(dev(img)).cpu().numpy(), want), (modes, val, sel)
             rag = np.ascontiguousarray(img[:, :, 3:])
-            assert np.array_equal(e.pipeline(dev(rag)).cpu().numpy(), np.stack([c_oracle.pipeline(luts, stages, modes, 3, im) for im in rag])), (modes, val, sel, "W=133")
+            assert np.array_equal(e.pipeline(dev(rag)).cpu().numpy(), np.stack([c_oracle.pipeline(luts, stages, modes, scale, im) for im in rag])), (modes, val, sel, "W=133")
             got2 = e.pipeline(dev(np.ascontiguousarray(img[..., :2]))).cpu().numpy()
             assert np.array_equal(got2, want[..., :2]), (modes, val, sel, "C=2")
             gotp = e.pipeline(dev(np.ascontiguousarray(img.transpose(0, 3, 1, 2))), layout=0).cpu().numpy()
             assert np.array_equal(gotp, want.transpose(0, 3, 1, 2)), (modes, val, sel, "planar")
             one = np.ascontiguousarray(img[0, :5, :3, :1])          # smaller than a window
-            assert np.array_equal(e.pipeline(dev(one)).cpu().numpy(), c_oracle.pipeline(luts, stages, modes, 3, one)), (modes, val, sel, "tiny")
+            assert np.array_equal(e.pipeline(dev(one)).cpu().numpy(), c_oracle.pipeline(luts, stages, modes, scale, one)), (modes, val, sel, "tiny")
         e.close()
 
 
