@@ -47,6 +47,21 @@ struct FtArgs {
     int di[kMaxFtModes][3], dj[kMaxFtModes][3];
 };
 
+// table row of every tube-band slot (-1: the slot holds no row), built at compile time: the flush of a workgroup's band sums walks the
+// slots instead of re-deriving (A, B, C, D) -> slot for 16 x 125 candidates per mode
+struct FtTubeRows { int row[kTubeSlots]; };
+constexpr FtTubeRows ft_make_tube_rows() {
+    FtTubeRows t{};
+    for (int i = 0; i < kTubeSlots; ++i) t.row[i] = -1;
+    for (int A = 0; A < kL; ++A)
+        for (int B = (A < 2 ? 0 : A - 2); B < kL && B <= A + 2; ++B)
+            for (int C = (A < 2 ? 0 : A - 2); C < kL && C <= A + 2; ++C)
+                for (int D = (A < 2 ? 0 : A - 2); D < kL && D <= A + 2; ++D)
+                    if (tube_contains(A, B, C, D)) t.row[tube_slot(A, B, C, D)] = A * kStrideA + B * kStrideB + C * kStrideC + D;
+    return t;
+}
+__device__ const FtTubeRows kFtTubeRows = ft_make_tube_rows();
+
 // the reference's tie-breaking: dimension ids (0=a,1=b,2=c,3=d) in descending order of f
 __device__ __forceinline__ void ft_order(float fa, float fb, float fc, float fd, int (&o)[4]) {
     const bool fab = fa > fb, fac = fa > fc, fad = fa > fd, fbc = fb > fc, fbd = fb > fd, fcd = fc > fd;
@@ -341,13 +356,11 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
         // flush the workgroup's tube-band sums: contiguous floats, a wave adds 256 bytes at a time
         for (int m = 0; m < a.M; ++m) {
             float *gtab = a.gw[m];
-            for (int A = 0; A < kL; ++A)      // tube rows of anchor MSB A: all (B, C, D) within two steps whose spread is <= 2
-                for (int i = threadIdx.x; i < 125; i += NT) {
-                    const int B = A - 2 + i / 25, C = A - 2 + (i / 5) % 5, D = A - 2 + i % 5;
-                    if (B < 0 || C < 0 || D < 0 || B >= kL || C >= kL || D >= kL || !tube_contains(A, B, C, D)) continue;
-                    const float v = s_band[m * kTubeSlots + tube_slot(A, B, C, D)];
-                    if (v != 0.0f) atomicAdd(&gtab[A * kStrideA + B * kStrideB + C * kStrideC + D], v);
-                }
+            for (int sl = threadIdx.x; sl < kTubeSlots; sl += NT) {
+                const int row = kFtTubeRows.row[sl];
+                const float v = s_band[m * kTubeSlots + sl];
+                if (row >= 0 && v != 0.0f) atomicAdd(&gtab[row], v);
+            }
         }
     }
 }
@@ -526,13 +539,11 @@ __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
         }
         lds_adds_done();
         __syncthreads();
-        for (int A = 0; A < kL; ++A)
-            for (int i = (int)threadIdx.x >> 4; i < 125; i += NT / 16) {
-                const int B = A - 2 + i / 25, C = A - 2 + (i / 5) % 5, D = A - 2 + i % 5;
-                if (B < 0 || C < 0 || D < 0 || B >= kL || C >= kL || D >= kL || !tube_contains(A, B, C, D)) continue;
-                const float v = s_band[tube_slot(A, B, C, D) * 16 + e];
-                if (v != 0.0f) atomicAdd(&gtab[(long long)(A * kStrideA + B * kStrideB + C * kStrideC + D) * EL + e], v);
-            }
+        for (int sl = grp; sl < kTubeSlots; sl += NG) {
+            const int row = kFtTubeRows.row[sl];
+            const float v = s_band[sl * 16 + e];
+            if (row >= 0 && v != 0.0f) atomicAdd(&gtab[(long long)row * EL + e], v);
+        }
         __syncthreads();
     }
     // the tile onto the image: position (ty, tx) is pixel (4 by - 2 + ty, 4 bx - 2 + tx) clamped into the plane

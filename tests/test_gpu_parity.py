@@ -306,18 +306,21 @@ def test_full_1080p_frame(eng, shipped_luts):
 # ---------------------------------------------------------------------------------------------
 # hipGraph capture (deep cascades are launch-bound at small frames; config 5 of BASELINE.json)
 # ---------------------------------------------------------------------------------------------
-def test_pipeline_replays_from_a_captured_graph():
-    stages, modes, scale = 4, "sdy", 2
+@pytest.mark.parametrize("stages,modes,scale,w", [(4, "sdy", 2, 77), (2, "sdy", 3, 76), (1, "yd", 3, 76)])
+def test_pipeline_replays_from_a_captured_graph(stages, modes, scale, w):
+    """(width 76: a multiple of four, i.e. the routed launch of the x2 / x3 final stages -- tile marks, memsets and the gather kernel's
+    launch on marked tiles are all inside the captured region)"""
     e = MuLUTEngine(0).configure(stages, modes, scale, 4)
     luts = {}
     for s in range(stages):
         for mode in modes:
             luts["s%d_%s" % (s + 1, mode)] = synthetic_lut(31 * s + ord(mode), scale * scale if s + 1 == stages else 1)
     e.set_lut_dict(luts)
-    img = np.random.default_rng(3).integers(0, 256, (2, 45, 77, 3), dtype=np.uint8)
+    img = np.random.default_rng(3).integers(0, 256, (2, 45, w, 3), dtype=np.uint8)
+    img[0, :, : w // 2] = natural_image(45, w // 2, 3, seed=4)         # smooth and noisy tiles in one frame
     x = dev(img)
-    out = torch.empty((2, 90, 154, 3), dtype=torch.uint8, device="cuda")
-    e.reserve(2, 45, 77, 3)                       # no allocation inside the captured region
+    out = torch.empty((2, 45 * scale, w * scale, 3), dtype=torch.uint8, device="cuda")
+    e.reserve(2, 45, w, 3)                        # no allocation inside the captured region
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         e.pipeline(x, out=out)                    # warm-up: kernel attributes are set on first launch
