@@ -62,19 +62,20 @@ constexpr FtTubeRows ft_make_tube_rows() {
 }
 __device__ const FtTubeRows kFtTubeRows = ft_make_tube_rows();
 
-// the reference's tie-breaking: dimension ids (0=a,1=b,2=c,3=d) in descending order of f
-__device__ __forceinline__ void ft_order(float fa, float fb, float fc, float fd, int (&o)[4]) {
-    const bool fab = fa > fb, fac = fa > fc, fad = fa > fd, fbc = fb > fc, fbd = fb > fd, fcd = fc > fd;
-    int code;   // four 2-bit ids, first in the low bits
-#define ORD(p, q, r, s) ((p) | ((q) << 2) | ((r) << 4) | ((s) << 6))
-    if (fab && fbc) code = fcd ? ORD(0, 1, 2, 3) : fbd ? ORD(0, 1, 3, 2) : fad ? ORD(0, 3, 1, 2) : ORD(3, 0, 1, 2);
-    else if (fab && fac) code = fbd ? ORD(0, 2, 1, 3) : fcd ? ORD(0, 2, 3, 1) : fad ? ORD(0, 3, 2, 1) : ORD(3, 0, 2, 1);
-    else if (fab) code = fbd ? ORD(2, 0, 1, 3) : fad ? ORD(2, 0, 3, 1) : fcd ? ORD(2, 3, 0, 1) : ORD(3, 2, 0, 1);
-    else if (fac) code = fcd ? ORD(1, 0, 2, 3) : fad ? ORD(1, 0, 3, 2) : fbd ? ORD(1, 3, 0, 2) : ORD(3, 1, 0, 2);
-    else if (fbc) code = fad ? ORD(1, 2, 0, 3) : fcd ? ORD(1, 2, 3, 0) : fbd ? ORD(1, 3, 2, 0) : ORD(3, 1, 2, 0);
-    else code = fad ? ORD(2, 1, 0, 3) : fbd ? ORD(2, 1, 3, 0) : fcd ? ORD(2, 3, 1, 0) : ORD(3, 2, 1, 0);
-#undef ORD
-    o[0] = code & 3; o[1] = (code >> 2) & 3; o[2] = (code >> 4) & 3; o[3] = (code >> 6) & 3;
+// The reference orders the four keys by a 24-branch cascade of strict '>' comparisons (sr/model.py:191-282).  For EVERY tie pattern that
+// cascade equals the stable order "f descending, on equal f the key with the higher index first" (exhaustive check over all orderings
+// and ties: tests/test_ft_order_cpu.py), so the rank of key i is the number of keys that come before it:
+//   rank_i = #{ j > i : f_j >= f_i } + #{ j < i : f_j > f_i }.
+// f lies in [0, 16): the int32 patterns of non-negative floats order like the floats, and [f_j < f_i] is the sign bit of their
+// difference -- the ranks are adds and shifts, no compare + select (a v_cndmask_b32 costs six full-rate instructions on this chip and
+// the cascade was ~20 of them per pass, the selects by rank below another ~36).
+// Returns the keys by rank, two bits each: key of rank j in bits 2j, 2j + 1.
+__device__ __forceinline__ int ft_order_code(float fa, float fb, float fc, float fd) {
+    const int a = __float_as_int(fa), b = __float_as_int(fb), c = __float_as_int(fc), d = __float_as_int(fd);
+    auto lt = [](int x, int y) { return (int)((unsigned)(x - y) >> 31); };      // [x < y] for 0 <= x, y < 2^31
+    const int s10 = lt(b, a), s20 = lt(c, a), s30 = lt(d, a), s21 = lt(c, b), s31 = lt(d, b), s32 = lt(d, c);
+    const int r1 = s10 + 2 - s21 - s31, r2 = s20 + s21 + 1 - s32, r3 = s30 + s31 + s32;      // (rank of key a: 3 - s10 - s20 - s30, contributes 0)
+    return (1 << (2 * r1)) | (2 << (2 * r2)) | (3 << (2 * r3));
 }
 
 struct FtPass {
@@ -106,27 +107,31 @@ __device__ __forceinline__ void ft_pass_setup(const float *plane, int H, int W, 
         h[k] = (int)hf;
         f[k] = v[k] - (float)kQ * hf;                    // img % q
     }
-    int o[4];
-    ft_order(f[0], f[1], f[2], f[3], o);
-    p.ord = o[0] | (o[1] << 2) | (o[2] << 4) | (o[3] << 6);
-    const int stride[4] = {kStrideA, kStrideB, kStrideC, kStrideD};
+    const int ord = ft_order_code(f[0], f[1], f[2], f[3]);
+    p.ord = ord;
+    // the LSBs by rank: only the VALUES are needed, and a min / max network sorts values whatever the ties
+    // (on the int32 patterns, as the ranks: integer min / max need no NaN canonicalisation of their operands)
     float fs[4];
-    int ss[4];
+    {
+        const int i0 = __float_as_int(f[0]), i1 = __float_as_int(f[1]), i2 = __float_as_int(f[2]), i3 = __float_as_int(f[3]);
+        const int a = imax(i0, i1), b = imin(i0, i1), c = imax(i2, i3), d = imin(i2, i3);
+        const int t1 = imin(a, c), t2 = imax(b, d);
+        fs[0] = __int_as_float(imax(a, c)); fs[1] = __int_as_float(imax(t1, t2)); fs[2] = __int_as_float(imin(t1, t2)); fs[3] = __int_as_float(imin(b, d));
+    }
+    // strides of the key of rank j: a shift of a packed constant by that key's id
+    constexpr unsigned long long kRowStrides = (unsigned long long)kStrideA | ((unsigned long long)kStrideB << 16) | ((unsigned long long)kStrideC << 32) |
+                                               ((unsigned long long)kStrideD << 48);
+    constexpr uint32_t kTubeStrides = (uint32_t)kTubeSA | ((uint32_t)kTubeSB << 8) | ((uint32_t)kTubeSC << 16) | ((uint32_t)kTubeSD << 24);
+    static_assert(kStrideA < 65536 && kTubeSA < 256 && kStrideD == 1, "packed stride constants");
+    int ss[4], ts[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {   // select without dynamic register indexing
-        const int d = o[j];
-        fs[j] = d == 0 ? f[0] : d == 1 ? f[1] : d == 2 ? f[2] : f[3];
-        ss[j] = d == 0 ? stride[0] : d == 1 ? stride[1] : d == 2 ? stride[2] : stride[3];
-        p.src[j] = d == 0 ? pix[0] : d == 1 ? pix[1] : d == 2 ? pix[2] : pix[3];
+    for (int j = 0; j < 4; ++j) {
+        const int d = (ord >> (2 * j)) & 3;
+        ss[j] = (int)((uint32_t)(kRowStrides >> (16 * d)) & 0xFFFFu);
+        ts[j] = (int)((kTubeStrides >> (8 * d)) & 0xFFu);
+        p.src[j] = d == 0 ? pix[0] : d == 1 ? pix[1] : d == 2 ? pix[2] : pix[3];      // (first-stage backward only; dead code elsewhere)
     }
     {
-        const int tstride[4] = {kTubeSA, kTubeSB, kTubeSC, kTubeSD};
-        int ts[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int d = o[j];
-            ts[j] = d == 0 ? tstride[0] : d == 1 ? tstride[1] : d == 2 ? tstride[2] : tstride[3];
-        }
         p.tslot[0] = tube_slot(h[0], h[1], h[2], h[3]);
         p.tslot[1] = p.tslot[0] + ts[0];
         p.tslot[2] = p.tslot[1] + ts[1];
