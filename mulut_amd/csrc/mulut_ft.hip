@@ -240,6 +240,17 @@ __device__ __forceinline__ void lds_add_f32(float *p, float v) {
 }
 __device__ __forceinline__ void lds_adds_done() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
 
+__device__ __forceinline__ float ft_sum16(float v) {      // sum over the 16 lanes of a DPP row; every lane gets it
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));      // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, true));      // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, true));      // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, true));      // row_ror:1
+    return v;
+}
+// lane K of every 16-lane row to all lanes of its row (v_mov_b32_dpp row_newbcast:K)
+template <int K> __device__ __forceinline__ int ft_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xF, 0xF, true); }
+template <int K> __device__ __forceinline__ float ft_bcast(float v) { return __int_as_float(ft_bcast<K>(__float_as_int(v))); }
+
 // Backward of one stage.  A workgroup owns 256 consecutive sites.  Per site (one thread): recompute the stage forward for
 // the clamp mask, g = dL/d pred; then per pass the five rows' dot products with g give the input gradient (one atomic
 // per rank into the source pixel: adjacent sites hit adjacent floats, i.e. well-shaped 256-byte atomic instructions).
@@ -310,10 +321,19 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
                 dsum[j] = acc;
                 const float wq = p.wt[j] / (float)kQ;
                 if constexpr (U == 1) {
-                    // one float per item: LDS tube band when the pass is inside the tube, else global memory
+                    // one float per item: LDS tube band when the pass is inside the tube, else global memory.  Neighbouring sites of smooth
+                    // content hit the SAME slot, and an LDS float add serialises over its lanes and again over equal addresses (this
+                    // kernel's LDS pipeline was busy 83 % of the launch on 96 such adds per site): the lanes of a 16-lane row that share
+                    // the row leader's slot are summed by DPP first and added once, by the leader; the others add on their own.
+                    // (All 256 threads are here: the broadcast and the row sum read every lane.)
                     const float v = wq * g[0];
-                    if (v != 0.0f) {
-                        if (p.in_tube) lds_add_f32(&s_band[m * kTubeSlots + p.tslot[j]], v);
+                    const int slot = p.in_tube ? m * kTubeSlots + p.tslot[j] : -1;
+                    const int lead = ft_bcast<0>(slot);
+                    const bool with_lead = slot == lead && slot >= 0;
+                    const float sum = ft_sum16(with_lead ? v : 0.0f);
+                    if ((threadIdx.x & 15) == 0 && lead >= 0 && sum != 0.0f) lds_add_f32(&s_band[lead], sum);
+                    if (!with_lead && v != 0.0f) {
+                        if (slot >= 0) lds_add_f32(&s_band[slot], v);
                         else atomicAdd(&gtab[p.idx[j]], v);
                     }
                 } else {
@@ -400,17 +420,6 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
 constexpr int kFtB4Sites = 512, kFtB4Groups = kFtB4Sites / 16;
 constexpr int kFtB4Lds = kTubeSlots * 16 * 4 + kFtB4Sites * 17 * 4 + kFtB4Groups * 16 * 16 * 4 + kFtB4Groups * 16 * 4 + kFtB4Groups * 64 * 4;
 static_assert(kFtB4Lds <= 160 * 1024, "ft_stage_bwd4: LDS");
-
-__device__ __forceinline__ float ft_sum16(float v) {      // sum over the 16 lanes of a DPP row; every lane gets it
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));      // row_ror:8
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, true));      // row_ror:4
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, true));      // row_ror:2
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, true));      // row_ror:1
-    return v;
-}
-// lane K of every 16-lane row to all lanes of its row (v_mov_b32_dpp row_newbcast:K)
-template <int K> __device__ __forceinline__ int ft_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xF, 0xF, true); }
-template <int K> __device__ __forceinline__ float ft_bcast(float v) { return __int_as_float(ft_bcast<K>(__float_as_int(v))); }
 
 __global__ void __launch_bounds__(kFtB4Sites) ft_stage_bwd4(FtArgs a) {
     constexpr int U = 4, EL = 16, NT = kFtB4Sites, NG = kFtB4Groups;
