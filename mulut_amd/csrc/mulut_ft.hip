@@ -81,7 +81,6 @@ __device__ __forceinline__ int ft_order_code(float fa, float fb, float fc, float
 struct FtPass {
     int idx[5];      // table rows of the five vertices
     float wt[5];     // q-f1, f1-f2, f2-f3, f3-f4, f4
-    int src[4];      // flat pixel index (within the channel plane) of the key of rank j
     int tslot[5];    // tube-band slots of the five vertices (mulut_core.h), valid when in_tube
     bool in_tube;    // the four MSBs span at most one step: every vertex lies in the 1041-slot tube band
     int ord;         // key (0 = a ... 3 = d) of rank j in bits 2j, 2j + 1
@@ -129,7 +128,6 @@ __device__ __forceinline__ void ft_pass_setup(const float *plane, int H, int W, 
         const int d = (ord >> (2 * j)) & 3;
         ss[j] = (int)((uint32_t)(kRowStrides >> (16 * d)) & 0xFFFFu);
         ts[j] = (int)((kTubeStrides >> (8 * d)) & 0xFFu);
-        p.src[j] = d == 0 ? pix[0] : d == 1 ? pix[1] : d == 2 ? pix[2] : pix[3];      // (first-stage backward only; dead code elsewhere)
     }
     {
         p.tslot[0] = tube_slot(h[0], h[1], h[2], h[3]);
@@ -260,7 +258,7 @@ template <int K> __device__ __forceinline__ float ft_bcast(float v) { return __i
 //   u == 1: one float per item: items inside the tube (991 rows, the ones smooth content uses) are summed into a
 //           per-workgroup LDS copy of the tube band with ds_add_f32 and flushed once per workgroup as contiguous
 //           atomics; items outside it go to global memory directly.
-constexpr int kFtGxFloats = 2048;      // LDS rows of the input gradient per workgroup (ft_stage_bwd)
+constexpr int kFtGxTile = 1024;        // floats of a wave's input-gradient tile (ft_stage_bwd)
 template <int U>
 __device__ __forceinline__ int eo_of_elem(int r, int e) {      // block position whose table element is e under rotation r (inverse of row_elem)
     return r == 0 ? e : r == 1 ? U * (e % U) + (U - 1 - e / U) : r == 2 ? U * U - 1 - e : U * (U - 1 - e % U) + e / U;
@@ -273,7 +271,7 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
     __shared__ int s_idx[5][NT];
     __shared__ float s_wq[5][NT];
     __shared__ float s_band[U == 1 ? kMaxFtModes * kTubeSlots : 1];
-    __shared__ float s_gx[kFtGxFloats];
+    __shared__ float s_gxt[NT / 64][kFtGxTile];
     const long long nsite = (long long)a.B * a.C * a.H * a.W;
     const long long s = (long long)blockIdx.x * NT + threadIdx.x;
     const bool valid = s < nsite;
@@ -282,15 +280,23 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
     const long long bc = sc / ((long long)a.W * a.H);
     const float *plane = a.x + bc * a.H * a.W;
     float *gplane = a.gx + bc * a.H * a.W;
-    // The input gradient gets 48 adds per site, into pixels at most two rows away.  The workgroup's sites are consecutive, so their
-    // targets lie in a few consecutive rows of the stacked image (planes one under the other = the memory layout of gx): those rows
-    // are summed in LDS and added to memory once per workgroup (memory-side float atomics were 0.6 ms of each backward kernel at
-    // bs 256 x 48 x 48).  Crops are small in fine-tuning (48 x 48); when the rows do not fit, the adds go to memory as before.
-    const long long gx_r0 = (long long)blockIdx.x * NT / a.W - 2;
-    const long long gx_r1 = (((long long)blockIdx.x * NT + NT - 1 < nsite ? (long long)blockIdx.x * NT + NT - 1 : nsite - 1)) / a.W + 2;
-    const int gx_n = (int)((gx_r1 - gx_r0 + 1) * a.W <= kFtGxFloats ? (gx_r1 - gx_r0 + 1) * a.W : 0);      // 0: does not fit
-    const int gx_off = (int)((bc * a.H - gx_r0) * a.W);       // index of a pixel in s_gx = its index in the plane + this
-    for (int i = threadIdx.x; i < gx_n; i += NT) s_gx[i] = 0.0f;
+    // The input gradient: a pass gives d/d f of each key to that key's pixel.  The site's own pixel (key a) is summed in a register; for
+    // key b, c or d the target is the site's pixel plus an offset that is the same for every site of the pass, so the 64 consecutive
+    // sites of a WAVE hit 64 different positions of the wave's private tile -- the rows its sites lie in plus two on either side, each
+    // plane with its own halo rows and columns (unclamped coordinates: replicate padding is applied when the tile is folded onto the
+    // image at the end): a plain LDS read + add + write per key, no atomic (36 LDS float adds per site before, 83 % of this kernel's
+    // launch with the LDS pipeline busy).  When the tile does not fit (crops wider than ~140) the adds go to memory.
+    const int lane = (int)threadIdx.x & 63;
+    float *tile = s_gxt[threadIdx.x >> 6];
+    const int PWd = a.W + 4, PHt = a.H + 4;
+    auto padded_row = [&](long long R) { return R + 4 * (R / a.H) + 2; };      // stacked image row (plane * H + y) -> row of the padded stack
+    const long long w0 = (long long)blockIdx.x * NT + (threadIdx.x & ~63u);
+    const long long R0 = (w0 < nsite ? w0 : nsite - 1) / a.W, R1 = (w0 + 63 < nsite ? w0 + 63 : nsite - 1) / a.W;
+    const long long pr0 = padded_row(R0) - 2;
+    const long long t_rows = padded_row(R1) + 2 - pr0 + 1;
+    const int t_n = t_rows * PWd <= kFtGxTile ? (int)(t_rows * PWd) : 0;      // 0: does not fit
+    for (int i = lane; i < t_n; i += 64) tile[i] = 0.0f;                      // (wave-private, and LDS serves a wave in order: no barrier)
+    const int t_own = (int)(padded_row(bc * a.H + y) - pr0) * PWd + x + 2;
     if constexpr (U == 1)
         for (int i = threadIdx.x; i < a.M * kTubeSlots; i += NT) s_band[i] = 0.0f;
     float g[EL];
@@ -341,13 +347,24 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
                     s_wq[j][threadIdx.x] = wq;
                 }
             }
+            // d/d f of rank j = (p_{j+1} - p_j) . g / q belongs to the key of that rank
+            float df[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {   // d/d f of rank j+1 = (p_{j+1} - p_j) . g / q
-                const float df = (dsum[j + 1] - dsum[j]) / (float)kQ;
-                if (p.src[j] == y * a.W + x) own += df;      // the site's own pixel is a key of every pass: summed here, added once
-                else if (df != 0.0f) {
-                    if (gx_n) lds_add_f32(&s_gx[p.src[j] + gx_off], df);
-                    else atomicAdd(&gplane[p.src[j]], df);
+            for (int j = 0; j < 4; ++j) df[j] = (dsum[j + 1] - dsum[j]) / (float)kQ;
+            const int o0 = p.ord & 3, o1 = (p.ord >> 2) & 3, o2 = (p.ord >> 4) & 3;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dk = o0 == k ? df[0] : o1 == k ? df[1] : o2 == k ? df[2] : df[3];
+                if (k == 0) own += dk;
+                else {
+                    int dy, dx;
+                    sample_offset(r, di[k - 1], dj[k - 1], dy, dx);
+                    if (t_n) {
+                        if (valid) {      // (a surplus thread shadows the last site: its read + add + write would race with that site's)
+                            float *t = tile + t_own + dy * PWd + dx;
+                            *t = *t + dk;
+                        }
+                    } else if (dk != 0.0f) atomicAdd(&gplane[imin(imax(y + dy, 0), a.H - 1) * a.W + imin(imax(x + dx, 0), a.W - 1)], dk);
                 }
             }
             if constexpr (U > 1) {
@@ -366,17 +383,20 @@ __global__ void __launch_bounds__(256) ft_stage_bwd(FtArgs a) {
             }
         }
     }
-    if (own != 0.0f) {
-        if (gx_n) lds_add_f32(&s_gx[y * a.W + x + gx_off], own);
-        else atomicAdd(&gplane[y * a.W + x], own);
-    }
+    // the wave's tile onto the image: padded row / column -> plane and pixel, clamped into the plane (replicate padding)
+    if (t_n) {
+        if (valid) tile[t_own] += own;
+        for (int i = lane; i < t_n; i += 64) {
+            const float v = tile[i];
+            if (v == 0.0f) continue;
+            const long long pr = pr0 + i / PWd;
+            const int cx = i % PWd - 2, yy = (int)(pr % PHt) - 2;
+            const long long pl = pr / PHt;
+            if (pl < (long long)a.B * a.C) atomicAdd(&a.gx[(pl * a.H + imin(imax(yy, 0), a.H - 1)) * a.W + imin(imax(cx, 0), a.W - 1)], v);
+        }
+    } else if (valid && own != 0.0f) atomicAdd(&gplane[y * a.W + x], own);
     lds_adds_done();
     __syncthreads();
-    for (int i = threadIdx.x; i < gx_n; i += NT) {      // the gradient rows: the stacked image IS gx's layout
-        const float v = s_gx[i];
-        const long long r = gx_r0 + i / a.W;
-        if (v != 0.0f && r >= 0 && r < (long long)a.B * a.C * a.H) atomicAdd(&a.gx[r * a.W + i % a.W], v);
-    }
     if constexpr (U == 1) {
         // flush the workgroup's tube-band sums: contiguous floats, a wave adds 256 bytes at a time
         for (int m = 0; m < a.M; ++m) {

@@ -118,7 +118,9 @@ def test_finetune_driver_reduces_loss_and_writes_luts(tmp_path):
 @pytest.mark.parametrize("stages,modes,scale,shape,kind", [
     (1, "y", 4, (2, 3, 5, 7), "u8"), (2, "sdy", 4, (1, 1, 1, 1), "u8"), (3, "sd", 2, (2, 1, 9, 6), "float"),
     (2, "dy", 3, (1, 2, 6, 8), "u8"), (2, "sdy", 4, (1, 1, 10, 10), "extreme"), (2, "s", 1, (1, 1, 7, 5), "float"),
-    (2, "sdy", 4, (256, 1, 48, 48), "smooth"), (2, "sdy", 4, (16, 1, 48, 48), "u8")])
+    (2, "sdy", 4, (256, 1, 48, 48), "smooth"), (2, "sdy", 4, (16, 1, 48, 48), "u8"),
+    # wide crops: a wave's input-gradient tile does not fit the LDS and the adds go to memory (ft_stage_bwd); planes of 3 rows
+    (2, "sdy", 4, (1, 2, 3, 300), "u8"), (2, "sd", 2, (1, 1, 4, 260), "float")])
 def test_more_shapes_vs_cpu_oracle(tmp_path, stages, modes, scale, shape, kind):
     """GPU module vs the pinned CPU oracle (oracle/ft_torch.py) on shapes / configurations the fixtures do not hold."""
     from mulut_amd.finetune import MuLUT
