@@ -133,6 +133,17 @@ __device__ __forceinline__ uint32_t win_pair(const uint32_t (&w)[5][NW]) {
     return __builtin_amdgcn_perm(w[R2][C2 / 2], w[R1][C1 / 2], sel);
 }
 
+// inclusive prefix sum over the 64 lanes of a wave: v_add_u32_dpp row_shr:1, 2, 4, 8 (zero fill) inside each row of 16, then the last
+// lane of row 0 / 2 into rows 1 / 3 (row_bcast:15, rows 1 and 3) and the last lane of row 1 into rows 2 and 3 (row_bcast:31)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);      // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);      // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);      // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);      // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    return x;
+}
 // LDS read at an integer byte address (address space 3 pointers are 32-bit offsets into the workgroup's allocation)
 __device__ __forceinline__ uint32_t lds_u32(uint32_t addr) {
     return *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)addr;

@@ -594,9 +594,9 @@ __global__ void __launch_bounds__(u1t_threads(U, PATS), u1t_waves(U, PATS)) stag
                     seen += 1;
                 }
             }
-            for (int o = 32; o > 0; o >>= 1) { far += __shfl_down(far, o); seen += __shfl_down(seen, o); }
+            far = wave_scan_add(far); seen = wave_scan_add(seen);      // the wave's totals in its last lane (DPP; as shuffles: twelve LDS permutes)
             __syncthreads();      // counters zeroed before anyone adds
-            if ((threadIdx.x & 63) == 0 && seen) { atomicAdd(&s_cnt[0], far); atomicAdd(&s_cnt[1], seen); }
+            if ((threadIdx.x & 63) == 63 && seen) { atomicAdd(&s_cnt[0], far); atomicAdd(&s_cnt[1], seen); }
             __syncthreads();
             if (s_cnt[0] * 1024u > detail_per_1024 * s_cnt[1]) {       // workgroup-uniform
                 if (threadIdx.x == 0) {      // verdict: left to the full-table kernel
@@ -767,19 +767,17 @@ __global__ void __launch_bounds__(u1t_threads(U, PATS), u1t_waves(U, PATS)) stag
                 bytes |= v << (4 * k);
                 mine += (uint32_t)__builtin_popcount(v);
             }
-            uint32_t inc = mine;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)inc, o);
-                if (lane >= o) inc += up;
-            }
+            // inclusive scan over the wave by DPP (four shifts inside the 16-lane rows, two row broadcasts): as __shfl_up steps it was six
+            // LDS permutes and twelve v_cndmask_b32 (12.6 issue cycles each) per tile and thread
+            const uint32_t inc = wave_scan_add(mine);
             if (lane == 63) s_scan[wave] = inc;
             __syncthreads();
             uint32_t wbase = 0, total = 0;
+            const int wave_s = __builtin_amdgcn_readfirstlane(wave);      // scalar: the selects below are then scalar too
 #pragma unroll
             for (int w = 0; w < NT / 64; ++w) {
-                const uint32_t v = s_scan[w];
-                wbase += w < wave ? v : 0u;
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_scan[w]);
+                wbase += w < wave_s ? v : 0u;
                 total += v;
             }
             if (total != 0u) {        // workgroup-uniform
