@@ -142,6 +142,11 @@ OPS(MK)
 #define A_MIXA(D) "v_and_b32 " D ", " D ", %8\n v_lshrrev_b32 %1, 4, %1\n v_mad_u32_u24 %2, %2, %8, %9\n v_perm_b32 %3, %3, %8, %9\n v_pk_mad_u16 %4, %4, %8, %9\n v_min_u32 %5, %5, %8\n v_max_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
 #define A_MIXB(D) "v_and_b32 " D ", " D ", %8\n v_lshrrev_b32 %1, 8, %1\n v_and_b32 %2, %2, %9\n v_pk_mad_u16 %3, %3, %8, %9\n v_pk_mad_u16 %4, %4, %8, %9\n v_and_b32 %5, %5, %8\n v_lshrrev_b32 %6, 8, %6\n v_pk_mad_u16 %7, %7, %8, %9\n"
 #define A_MIXC(D) "v_pk_max_u16 " D ", " D ", %8\n v_pk_min_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n v_pk_sub_u16 %3, %3, %8\n v_pk_lshrrev_b16 %4, 12, %4\n v_and_b32 %5, %5, %8\n v_pk_mad_u16 %6, %6, %8, %9\n v_add_u32_sdwa %7, %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+// the instructions of MIXB (five full-rate, three half-rate), the full-rate ones first: does a RUN of full-rate instructions issue at their rate?
+#define A_MIXD(D) "v_and_b32 " D ", " D ", %8\n v_lshrrev_b32 %1, 8, %1\n v_and_b32 %2, %2, %9\n v_and_b32 %5, %5, %8\n v_lshrrev_b32 %6, 8, %6\n v_pk_mad_u16 %3, %3, %8, %9\n v_pk_mad_u16 %4, %4, %8, %9\n v_pk_mad_u16 %7, %7, %8, %9\n"
+// runs of sixteen: eight full-rate instructions twice, then eight half-rate ones twice (DEFMIX2 below)
+#define A_FAST8(D) "v_and_b32 " D ", " D ", %8\n v_lshrrev_b32 %1, 8, %1\n v_and_b32 %2, %2, %9\n v_and_b32 %5, %5, %8\n v_lshrrev_b32 %6, 8, %6\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %7, %7, %8\n"
+#define A_SLOW8(D) "v_pk_mad_u16 " D ", " D ", %8, %9\n v_pk_mad_u16 %1, %1, %8, %9\n v_pk_mad_u16 %2, %2, %8, %9\n v_pk_mad_u16 %3, %3, %8, %9\n v_pk_mad_u16 %4, %4, %8, %9\n v_pk_mad_u16 %5, %5, %8, %9\n v_pk_mad_u16 %6, %6, %8, %9\n v_pk_mad_u16 %7, %7, %8, %9\n"
 #define DEPOPS(X) X(ADD) X(AND) X(MIN) X(MAD24) X(PKMAD) X(PKMIN) X(PERM) X(LSHLOR) X(FMA) X(CVTF)
 #define MKD(N) DEFDEP(N, A_##N)
 DEPOPS(MKD)
@@ -165,12 +170,30 @@ DEPOPS(MKD)
 DEFMIX(MIXA, A_MIXA)
 DEFMIX(MIXB, A_MIXB)
 DEFMIX(MIXC, A_MIXC)
+DEFMIX(MIXD, A_MIXD)
+#define DEFMIX2(NAME, GA, GB)                                                                        \
+    __global__ void __launch_bounds__(1024) k_##NAME(unsigned long long *cyc, uint32_t *sink, int iters) { \
+        uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        uint32_t b = threadIdx.x * 3u + 7u, c = threadIdx.x ^ 0x55u;                                  \
+        __syncthreads();                                                                              \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                         \
+        for (int i = 0; i < iters; ++i) {                                                             \
+            asm volatile(GA("%0") GA("%0") GB("%0") GB("%0")                                           \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)     \
+                         : "v"(b), "v"(c));                                                           \
+        }                                                                                             \
+        asm volatile("s_nop 0" ::: "memory");                                                         \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                         \
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;          \
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;             \
+    }
+DEFMIX2(MIXE, A_FAST8, A_SLOW8)
 
 typedef void (*kfn)(unsigned long long *, uint32_t *, int);
 struct Ent { const char *name; kfn fn; };
 #define ENT(N) {#N, k_##N},
 #define ENTD(N) {"dep_" #N, d_##N},
-static Ent ents[] = {OPS(ENT) DEPOPS(ENTD) {"MIXA", k_MIXA}, {"MIXB", k_MIXB}, {"MIXC", k_MIXC}};
+static Ent ents[] = {OPS(ENT) DEPOPS(ENTD) {"MIXA", k_MIXA}, {"MIXB", k_MIXB}, {"MIXC", k_MIXC}, {"MIXD", k_MIXD}, {"MIXE", k_MIXE}};
 
 int main(int argc, char **argv) {
     hipDeviceProp_t prop;
