@@ -239,10 +239,11 @@ constexpr int K1T_TW = 64, K1T_TH = 64;
 // Threads per workgroup (a thread owns four adjacent pixels of a row: 1024 take the 64 x 64 tile at once, 512 in two halves of 32 rows) and
 // waves per SIMD.  The instance with the shipped mode list compiled in needs 59 VGPRs: two 1024-thread workgroups share a CU at 8 waves per
 // SIMD (the half-rate instruction class issues at 2.62 cycles per instruction and SIMD there, 2.83 at 6: profiles/r01_ubench_valu_issue_cost.txt).
-// The run-time-list instances need 80: three 512-thread workgroups, 6 waves per SIMD.
+// The u == 2 instance with the shipped list fits 62 VGPRs and 56 KB of LDS: the same two 1024-thread workgroups per CU (round 4; 67 VGPRs at
+// three 512-thread workgroups before).  The run-time-list instances need 80: three 512-thread workgroups, 6 waves per SIMD.
 // u == 3 (24,992-byte bands: one workgroup per CU): 1024 threads, 4 waves per SIMD.
-__host__ __device__ constexpr int u1t_threads(int U, int pats) { return ((U == 1 && pats != 0) || U == 3) ? 1024 : 512; }
-__host__ __device__ constexpr int u1t_waves(int U, int pats) { return U == 3 ? 4 : (U == 1 && pats != 0) ? 8 : 6; }
+__host__ __device__ constexpr int u1t_threads(int U, int pats) { return ((U <= 2 && pats != 0) || U == 3) ? 1024 : 512; }
+__host__ __device__ constexpr int u1t_waves(int U, int pats) { return U == 3 ? 4 : (U <= 2 && pats != 0) ? 8 : 6; }
 constexpr int K1T_PW = K1T_TW + 2 * kHalo, K1T_PH = K1T_TH + 2 * kHalo;
 constexpr int kU1tTileBytes = 3 * K1T_PH * K1T_PW * 2;
 constexpr int kU1tDirtyBytes = 3 * K1T_TH * (K1T_TW / 4);          // one byte per four-pixel group of the tile
