@@ -556,6 +556,11 @@ def test_x3_final_stage_on_the_lds_path(scale, stages, modes):
             assert np.array_equal(got2, want[..., :2]), (modes, val, sel, "C=2")
             gotp = e.pipeline(dev(np.ascontiguousarray(img.transpose(0, 3, 1, 2))), layout=0).cpu().numpy()
             assert np.array_equal(gotp, want.transpose(0, 3, 1, 2)), (modes, val, sel, "planar")
+            if sel == 0:            # the routed launch at its extremes: every tile left to the gather kernel, every tile kept
+                for thr in (0, 1024):
+                    e.set_tuning("final_stage_detail_per_1024", thr)
+                    assert np.array_equal(e.pipeline(dev(img)).cpu().numpy(), want), (modes, val, "threshold", thr)
+                e.set_tuning("final_stage_detail_per_1024", 8)
             one = np.ascontiguousarray(img[0, :5, :3, :1])          # smaller than a window
             assert np.array_equal(e.pipeline(dev(one)).cpu().numpy(), c_oracle.pipeline(luts, stages, modes, scale, one)), (modes, val, sel, "tiny")
         e.close()
